@@ -1,0 +1,118 @@
+/*
+ * micromix_hip.h -- C ABI of libmicromix_hip.so (MI355X / gfx950 only).
+ *
+ * Drop-in boundary for the MicroMix `mixedgemm` extension's MX hot path.  Every
+ * entry point takes plain device pointers, sizes and a HIP stream; no torch
+ * types.  The caller (the Python `mixedgemm` module, or a C++/pybind binding a
+ * reference maintainer writes) owns allocation, shape
+ * derivation and stream/device selection.
+ *
+ * Reference interfaces replaced (paths relative to the MicroMix tree):
+ *   mm_reorder_quantize  <- run_reorder_quantize_x   mgemm/src/reorder.cu:434-469
+ *                           run_reorder_quantize_w   mgemm/src/reorder.cu:471-506
+ *                           run_reorder_quantize_w4  mgemm/src/reorder.cu:508-543
+ *                           (bindings: mgemm/src/bindings.cpp:104-151,155-202,206-253)
+ *   mm_matmul            <- matmul_host / matmul_w4_host   mgemm/src/gemm.cu:26-78
+ *                           (binding: mgemm/src/bindings.cpp:50-102)
+ *   mm_sf_bytes_x / _w   <- SF allocation sizes      mgemm/src/bindings.cpp:120-123,170-172
+ *   mm_sf_offset         <- SF layout atom            mgemm/include/sm120_sf_layout.h:170-173
+ *
+ * All functions are asynchronous with respect to the host (kernels are queued
+ * on `stream`) and return an mm_status code; they never exit() or abort().
+ */
+#ifndef MICROMIX_HIP_H
+#define MICROMIX_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *mm_stream_t; /* hipStream_t */
+
+enum mm_status {
+    MM_OK = 0,
+    MM_ERR_BAD_SPLIT = 1,   /* KN+KS+KO != K, or not multiples of 128 (reference: "Value error in run_reorder_quantize_*") */
+    MM_ERR_BAD_ARG = 2,     /* null pointer / negative size / K too large for int16 indices */
+    MM_ERR_LAUNCH = 3,      /* HIP launch error; text via mm_last_error() */
+    MM_ERR_UNSUPPORTED = 4, /* configuration not built */
+    MM_ERR_NO_DEVICE = 5    /* no gfx950 device */
+};
+
+/* mode argument of mm_reorder_quantize */
+enum mm_quant_mode {
+    MM_QUANT_MIXED = 0, /* segments -> MXFP4 | MXFP6(E3M2) | MXFP8(E4M3)   (reorder_quantize_x / _w)  */
+    MM_QUANT_W4 = 1     /* segments -> MXFP4 | MXFP4 | MXFP4                (reorder_quantize_w4)       */
+};
+
+/* wmode argument of mm_matmul: format of the B (weight) segments */
+enum mm_weight_mode {
+    MM_W_MATCH = 0, /* B = fp4 | fp6 | fp8  (matmul_host,    gemm.cu:26-51) */
+    MM_W_FP4 = 1    /* B = fp4 | fp4 | fp4  (matmul_w4_host, gemm.cu:53-78) */
+};
+
+/* flags argument of mm_matmul */
+enum mm_matmul_flags {
+    MM_ROUND_PER_SEGMENT = 0, /* default: accumulator rounded through bf16 after each segment, as the
+                                 reference's three chained kernels do (gemm.cu:75-77) */
+    MM_ROUND_ONCE = 1         /* single fp32 accumulator across segments, one bf16 rounding */
+};
+
+int mm_version(void);
+const char *mm_strerror(int status);
+/* Text of the last HIP error seen by this thread ("" if none). */
+const char *mm_last_error(void);
+
+/* Scale-factor tensor geometry (one tensor per segment). */
+size_t mm_sf_bytes_x(int M, int Kseg); /* (M/128+1)*128 * Kseg/32, bindings.cpp:120-123 */
+size_t mm_sf_bytes_w(int N, int Kseg); /* ceil(N/128)*128 * Kseg/32, bindings.cpp:170-172 */
+size_t mm_sf_offset(int row, int block, int Kseg);
+
+/*
+ * Fused column-reorder + per-32-group absmax + E8M0 scale + MXFP4/6/8 quantize + pack.
+ *   src_bf16       [rows, K] bf16, row-major, contiguous
+ *   reorder_index  [K] int16: output column j takes input column reorder_index[j]
+ *   KN,KS,KO       widths of the three reordered segments; multiples of 128; KN+KS+KO == K
+ *   oN [rows,KN/2]; oS [rows,3*KS/4] (mixed) or [rows,KS/2] (w4); oO [rows,KO] (mixed) or [rows,KO/2] (w4)
+ *   sfN,sfS,sfO    UE8M0 bytes in the layout of mm_sf_offset; buffers of at least
+ *                  mm_sf_bytes_x(rows,Kseg) (activations) / mm_sf_bytes_w(rows,Kseg) (weights) bytes.
+ *                  Only the bytes of real rows are written (the reference leaves padding uninitialised).
+ * Pointers of zero-width segments may be NULL.
+ */
+int mm_reorder_quantize(const void *src_bf16, int rows, int K, const int16_t *reorder_index, int KN, int KS, int KO,
+                        int mode, uint8_t *oN, uint8_t *oS, uint8_t *oO, uint8_t *sfN, uint8_t *sfS, uint8_t *sfO,
+                        mm_stream_t stream);
+
+/*
+ * Three-segment mixed-precision block-scaled GEMM:
+ *   D[m,n] = bf16( sum over segments, blocks b:  2^(sfa[m,b]-127) * 2^(sfb[n,b]-127) * sum_{k in b} a[m,k]*b[n,k] ) (+ bias[n])
+ *   A segments: AN [M,KN/2] fp4, AS [M,3KS/4] fp6(E3M2), AO [M,KO] fp8(E4M3)
+ *   B segments: wmode MM_W_MATCH: same formats as A;  MM_W_FP4: all fp4 ([N,Kseg/2])
+ *   bias_bf16   optional [N] bf16 (NULL for none), added after the final rounding and rounded
+ *               again, i.e. exactly `y = matmul(...); y = y + bias` (qLinearLayer.py:68-71)
+ *   D_bf16      [M,N] bf16 row-major; fully overwritten (no pre-zeroing needed)
+ */
+int mm_matmul(const uint8_t *AN, const uint8_t *BN, const uint8_t *AS, const uint8_t *BS, const uint8_t *AO,
+              const uint8_t *BO, const uint8_t *SFAN, const uint8_t *SFBN, const uint8_t *SFAS, const uint8_t *SFBS,
+              const uint8_t *SFAO, const uint8_t *SFBO, int M, int N, int KN, int KS, int KO, int wmode, int flags,
+              const void *bias_bf16, void *D_bf16, mm_stream_t stream);
+
+/*
+ * Hardware diagnostics (not on the product path; used by the GPU tests to pin register
+ * layouts and the oracle's encoders against the CDNA4 hardware).
+ *   mm_diag_mfma: one wave issues one v_mfma_scale_f32_{32x32x64,16x16x128}_f8f6f4.
+ *     shape 32|16; el_a/el_b 0=fp4 1=fp6(E3M2) 2=fp8(E4M3); opsel 0..3 applied to both scales;
+ *     a_regs/b_regs [64 lanes][8] int32; scale_a/scale_b [64] int32; out [64][16|4] float.
+ *   mm_diag_hw_convert: v_cvt_scalef32_pk_{fp4,fp8}_bf16 / pk32_bf6_bf16 on n (multiple of 32)
+ *     bf16 values with one scale; out_codes gets one element code per byte.
+ */
+int mm_diag_mfma(int shape, int el_a, int el_b, int opsel, const void *a_regs, const void *b_regs, const void *scale_a,
+                 const void *scale_b, void *out, mm_stream_t stream);
+int mm_diag_hw_convert(const void *src_bf16, int n, float scale, int el, uint8_t *out_codes, mm_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MICROMIX_HIP_H */

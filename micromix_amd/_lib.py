@@ -1,0 +1,80 @@
+"""ctypes binding of libmicromix_hip.so (the C ABI declared in include/micromix_hip.h).
+
+There is deliberately NO fallback: if the HIP library is missing or fails to load, every
+op raises.  A CPU path would silently void the parity claims of the GPU tests.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "lib", "libmicromix_hip.so")
+
+# every symbol include/micromix_hip.h declares
+EXPORTS = (
+    "mm_version", "mm_strerror", "mm_last_error",
+    "mm_sf_bytes_x", "mm_sf_bytes_w", "mm_sf_offset",
+    "mm_reorder_quantize", "mm_matmul",
+    "mm_diag_mfma", "mm_diag_hw_convert",
+)
+
+MM_OK, MM_ERR_BAD_SPLIT, MM_ERR_BAD_ARG, MM_ERR_LAUNCH, MM_ERR_UNSUPPORTED, MM_ERR_NO_DEVICE = range(6)
+MM_QUANT_MIXED, MM_QUANT_W4 = 0, 1
+MM_W_MATCH, MM_W_FP4 = 0, 1
+MM_ROUND_PER_SEGMENT, MM_ROUND_ONCE = 0, 1
+
+_lib = None
+
+
+class MicroMixLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and return the ctypes handle; raises if the library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MicroMixLibraryError(
+            f"{LIB_PATH} is missing: build it with `python -m micromix_amd.build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, i, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
+    lib.mm_version.restype = i
+    lib.mm_version.argtypes = []
+    lib.mm_strerror.restype = ctypes.c_char_p
+    lib.mm_strerror.argtypes = [i]
+    lib.mm_last_error.restype = ctypes.c_char_p
+    lib.mm_last_error.argtypes = []
+    lib.mm_sf_bytes_x.restype = sz
+    lib.mm_sf_bytes_x.argtypes = [i, i]
+    lib.mm_sf_bytes_w.restype = sz
+    lib.mm_sf_bytes_w.argtypes = [i, i]
+    lib.mm_sf_offset.restype = sz
+    lib.mm_sf_offset.argtypes = [i, i, i]
+    lib.mm_reorder_quantize.restype = i
+    lib.mm_reorder_quantize.argtypes = [vp, i, i, vp, i, i, i, i, vp, vp, vp, vp, vp, vp, vp]
+    lib.mm_matmul.restype = i
+    lib.mm_matmul.argtypes = [vp] * 12 + [i] * 7 + [vp, vp, vp]
+    lib.mm_diag_mfma.restype = i
+    lib.mm_diag_mfma.argtypes = [i, i, i, i, vp, vp, vp, vp, vp, vp]
+    lib.mm_diag_hw_convert.restype = i
+    lib.mm_diag_hw_convert.argtypes = [vp, i, ctypes.c_float, i, vp, vp]
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str):
+    """Map an mm_status to the exception the reference's binding raises."""
+    if status == MM_OK:
+        return
+    lib = load()
+    msg = lib.mm_strerror(status).decode()
+    if status == MM_ERR_BAD_SPLIT:
+        # reference: throw std::runtime_error("Value error in run_reorder_quantize_x") (bindings.cpp:145-148)
+        raise RuntimeError(f"Value error in run_{what}: {msg}")
+    if status == MM_ERR_LAUNCH:
+        raise RuntimeError(f"{what}: {msg}: {lib.mm_last_error().decode()}")
+    raise RuntimeError(f"{what}: {msg}")

@@ -1,0 +1,89 @@
+// extern "C" surface of libmicromix_hip.so -- see include/micromix_hip.h.
+#include "../../include/micromix_hip.h"
+#include "mx_common.h"
+#include "mx_kernels.h"
+
+#include <stdio.h>
+#include <string.h>
+
+
+static thread_local char g_last_error[256] = "";
+
+static int fail_hip(hipError_t e, const char *where) {
+    snprintf(g_last_error, sizeof(g_last_error), "%s: %s", where, hipGetErrorString(e));
+    return MM_ERR_LAUNCH;
+}
+
+static bool split_ok(int K, int KN, int KS, int KO) {
+    return KN >= 0 && KS >= 0 && KO >= 0 && (KN % 128) == 0 && (KS % 128) == 0 && (KO % 128) == 0 && KN + KS + KO == K &&
+           K > 0;
+}
+
+extern "C" {
+
+int mm_version(void) { return 100; /* 0.1.0 */ }
+
+const char *mm_strerror(int status) {
+    switch (status) {
+        case MM_OK: return "ok";
+        case MM_ERR_BAD_SPLIT: return "KN, KS, KO must be non-negative multiples of 128 that sum to K";
+        case MM_ERR_BAD_ARG: return "bad argument";
+        case MM_ERR_LAUNCH: return "HIP error";
+        case MM_ERR_UNSUPPORTED: return "unsupported configuration";
+        case MM_ERR_NO_DEVICE: return "no gfx950 device";
+        default: return "unknown status";
+    }
+}
+
+const char *mm_last_error(void) { return g_last_error; }
+
+size_t mm_sf_bytes_x(int M, int Kseg) { return (size_t)(M / 128 + 1) * 128u * (size_t)(Kseg / 32); }
+size_t mm_sf_bytes_w(int N, int Kseg) { return (size_t)((N + 127) / 128) * 128u * (size_t)(Kseg / 32); }
+size_t mm_sf_offset(int row, int block, int Kseg) { return mm::sf_offset(row, block, Kseg); }
+
+int mm_reorder_quantize(const void *src_bf16, int rows, int K, const int16_t *reorder_index, int KN, int KS, int KO,
+                        int mode, uint8_t *oN, uint8_t *oS, uint8_t *oO, uint8_t *sfN, uint8_t *sfS, uint8_t *sfO,
+                        mm_stream_t stream) {
+    if (!split_ok(K, KN, KS, KO)) return MM_ERR_BAD_SPLIT;
+    if (rows < 0 || K > 32768 || (mode != MM_QUANT_MIXED && mode != MM_QUANT_W4)) return MM_ERR_BAD_ARG;
+    if (rows == 0) return MM_OK;
+    if (!src_bf16 || !reorder_index) return MM_ERR_BAD_ARG;
+    if ((KN && (!oN || !sfN)) || (KS && (!oS || !sfS)) || (KO && (!oO || !sfO))) return MM_ERR_BAD_ARG;
+    hipError_t e = mm::launch_reorder_quantize(src_bf16, rows, K, reorder_index, KN, KS, KO, mode == MM_QUANT_W4, oN, oS,
+                                               oO, sfN, sfS, sfO, (hipStream_t)stream);
+    return e == hipSuccess ? MM_OK : fail_hip(e, "mm_reorder_quantize");
+}
+
+int mm_matmul(const uint8_t *AN, const uint8_t *BN, const uint8_t *AS, const uint8_t *BS, const uint8_t *AO,
+              const uint8_t *BO, const uint8_t *SFAN, const uint8_t *SFBN, const uint8_t *SFAS, const uint8_t *SFBS,
+              const uint8_t *SFAO, const uint8_t *SFBO, int M, int N, int KN, int KS, int KO, int wmode, int flags,
+              const void *bias_bf16, void *D_bf16, mm_stream_t stream) {
+    if (M < 0 || N < 0 || KN < 0 || KS < 0 || KO < 0) return MM_ERR_BAD_ARG;
+    if ((KN % 128) || (KS % 128) || (KO % 128)) return MM_ERR_BAD_SPLIT;
+    if (wmode != MM_W_MATCH && wmode != MM_W_FP4) return MM_ERR_BAD_ARG;
+    if (M == 0 || N == 0) return MM_OK;
+    if (!D_bf16) return MM_ERR_BAD_ARG;
+    if ((KN && (!AN || !BN || !SFAN || !SFBN)) || (KS && (!AS || !BS || !SFAS || !SFBS)) ||
+        (KO && (!AO || !BO || !SFAO || !SFBO)))
+        return MM_ERR_BAD_ARG;
+    if (KN + KS + KO == 0) {  // reference: C = zeros, no segment runs (gemm.cu:48-50)
+        hipError_t e = hipMemsetAsync(D_bf16, 0, (size_t)M * N * 2, (hipStream_t)stream);
+        return e == hipSuccess ? MM_OK : fail_hip(e, "mm_matmul(memset)");
+    }
+    mm::GemmArgs a;
+    a.X[0] = AN; a.X[1] = AS; a.X[2] = AO;
+    a.W[0] = BN; a.W[1] = BS; a.W[2] = BO;
+    a.SFX[0] = SFAN; a.SFX[1] = SFAS; a.SFX[2] = SFAO;
+    a.SFW[0] = SFBN; a.SFW[1] = SFBS; a.SFW[2] = SFBO;
+    a.K[0] = KN; a.K[1] = KS; a.K[2] = KO;
+    a.M = M; a.N = N;
+    a.sfx_row_tiles = M / 128 + 1;
+    a.sfw_row_tiles = (N + 127) / 128;
+    a.round_per_segment = (flags & MM_ROUND_ONCE) ? 0 : 1;
+    a.bias = (const uint16_t *)bias_bf16;
+    a.D = (uint16_t *)D_bf16;
+    hipError_t e = mm::launch_mx_gemm(a, wmode == MM_W_FP4, (hipStream_t)stream);
+    return e == hipSuccess ? MM_OK : fail_hip(e, "mm_matmul");
+}
+
+}  // extern "C"

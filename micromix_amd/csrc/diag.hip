@@ -1,0 +1,142 @@
+// Hardware diagnostics exported through the C ABI (mm_diag_*): single scaled-MFMA issue and the
+// CDNA4 MX converter instructions, so that the tests can pin (a) the operand/scale/accumulator
+// register layouts the GEMM kernel relies on and (b) the oracle's element encoders against
+// AMD's own hardware implementation of the OCP MX formats.  Not on the product path.
+#include "../../include/micromix_hip.h"
+#include "mx_common.h"
+
+namespace mm {
+
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+template <int FA, int FB, int OPSEL>
+__global__ void diag_mfma32(const v8i *a, const v8i *b, const int *sa, const int *sb, v16f *out) {
+    const int l = threadIdx.x;
+    v16f acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[l], b[l], acc, FA, FB, OPSEL, sa[l], OPSEL, sb[l]);
+    out[l] = acc;
+}
+
+template <int FA, int FB, int OPSEL>
+__global__ void diag_mfma16(const v8i *a, const v8i *b, const int *sa, const int *sb, v4f *out) {
+    const int l = threadIdx.x;
+    v4f acc = {0.0f, 0.0f, 0.0f, 0.0f};
+    acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a[l], b[l], acc, FA, FB, OPSEL, sa[l], OPSEL, sb[l]);
+    out[l] = acc;
+}
+
+template <int FA, int FB, int OPSEL>
+static void launch_mfma(int shape, const void *a, const void *b, const void *sa, const void *sb, void *out, hipStream_t s) {
+    if (shape == 32)
+        hipLaunchKernelGGL((diag_mfma32<FA, FB, OPSEL>), dim3(1), dim3(64), 0, s, (const v8i *)a, (const v8i *)b,
+                           (const int *)sa, (const int *)sb, (v16f *)out);
+    else
+        hipLaunchKernelGGL((diag_mfma16<FA, FB, OPSEL>), dim3(1), dim3(64), 0, s, (const v8i *)a, (const v8i *)b,
+                           (const int *)sa, (const int *)sb, (v4f *)out);
+}
+
+template <int FA, int FB>
+static void dispatch_opsel(int shape, int opsel, const void *a, const void *b, const void *sa, const void *sb, void *out,
+                           hipStream_t s) {
+    switch (opsel) {
+        case 0: launch_mfma<FA, FB, 0>(shape, a, b, sa, sb, out, s); break;
+        case 1: launch_mfma<FA, FB, 1>(shape, a, b, sa, sb, out, s); break;
+        case 2: launch_mfma<FA, FB, 2>(shape, a, b, sa, sb, out, s); break;
+        default: launch_mfma<FA, FB, 3>(shape, a, b, sa, sb, out, s); break;
+    }
+}
+
+template <int FA>
+static void dispatch_fb(int fb, int shape, int opsel, const void *a, const void *b, const void *sa, const void *sb,
+                        void *out, hipStream_t s) {
+    switch (fb) {
+        case EL_FP4: dispatch_opsel<FA, HW_FP4>(shape, opsel, a, b, sa, sb, out, s); break;
+        case EL_FP6: dispatch_opsel<FA, HW_BF6>(shape, opsel, a, b, sa, sb, out, s); break;
+        default: dispatch_opsel<FA, HW_FP8>(shape, opsel, a, b, sa, sb, out, s); break;
+    }
+}
+
+typedef __bf16 v2bf __attribute__((ext_vector_type(2)));
+typedef __bf16 v32bf __attribute__((ext_vector_type(32)));
+typedef unsigned v6u __attribute__((ext_vector_type(6)));
+typedef short v2s __attribute__((ext_vector_type(2)));
+
+// one thread converts one 32-element group with the hardware MX converters; writes one code per byte
+__global__ void diag_hw_convert(const uint16_t *src, int ngroups, float scale, int el, uint8_t *out) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= ngroups) return;
+    const uint16_t *p = src + (size_t)g * 32;
+    uint8_t *o = out + (size_t)g * 32;
+    if (el == EL_FP4) {
+        for (int i = 0; i < 32; i += 8) {
+            unsigned w = 0;
+            v2bf x0, x1, x2, x3;
+            __builtin_memcpy(&x0, p + i, 4);
+            __builtin_memcpy(&x1, p + i + 2, 4);
+            __builtin_memcpy(&x2, p + i + 4, 4);
+            __builtin_memcpy(&x3, p + i + 6, 4);
+            w = __builtin_amdgcn_cvt_scalef32_pk_fp4_bf16(w, x0, scale, 0);
+            w = __builtin_amdgcn_cvt_scalef32_pk_fp4_bf16(w, x1, scale, 1);
+            w = __builtin_amdgcn_cvt_scalef32_pk_fp4_bf16(w, x2, scale, 2);
+            w = __builtin_amdgcn_cvt_scalef32_pk_fp4_bf16(w, x3, scale, 3);
+            for (int k = 0; k < 8; ++k) o[i + k] = (w >> (4 * k)) & 0xF;
+        }
+    } else if (el == EL_FP8) {
+        for (int i = 0; i < 32; i += 4) {
+            v2s w = {0, 0};
+            v2bf x0, x1;
+            __builtin_memcpy(&x0, p + i, 4);
+            __builtin_memcpy(&x1, p + i + 2, 4);
+            w = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(w, x0, scale, false);
+            w = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(w, x1, scale, true);
+            unsigned u;
+            __builtin_memcpy(&u, &w, 4);
+            for (int k = 0; k < 4; ++k) o[i + k] = (u >> (8 * k)) & 0xFF;
+        }
+    } else {
+        v32bf x;
+        __builtin_memcpy(&x, p, 64);
+        v6u w = __builtin_amdgcn_cvt_scalef32_pk32_bf6_bf16(x, scale);
+        unsigned long long lo = (unsigned long long)w[0] | ((unsigned long long)w[1] << 32);
+        unsigned long long mi = (unsigned long long)w[2] | ((unsigned long long)w[3] << 32);
+        unsigned long long hi = (unsigned long long)w[4] | ((unsigned long long)w[5] << 32);
+        unsigned long long ws[3] = {lo, mi, hi};
+        for (int i = 0; i < 32; ++i) {
+            const int bit = 6 * i, word = bit >> 6, off = bit & 63;
+            unsigned long long v = ws[word] >> off;
+            if (off > 58) v |= ws[word + 1] << (64 - off);
+            o[i] = (uint8_t)(v & 0x3F);
+        }
+    }
+}
+
+}  // namespace mm
+
+extern "C" {
+
+int mm_diag_mfma(int shape, int el_a, int el_b, int opsel, const void *a_regs, const void *b_regs, const void *scale_a,
+                 const void *scale_b, void *out, mm_stream_t stream) {
+    if ((shape != 32 && shape != 16) || el_a < 0 || el_a > 2 || el_b < 0 || el_b > 2 || opsel < 0 || opsel > 3)
+        return MM_ERR_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    switch (el_a) {
+        case mm::EL_FP4: mm::dispatch_fb<mm::HW_FP4>(el_b, shape, opsel, a_regs, b_regs, scale_a, scale_b, out, s); break;
+        case mm::EL_FP6: mm::dispatch_fb<mm::HW_BF6>(el_b, shape, opsel, a_regs, b_regs, scale_a, scale_b, out, s); break;
+        default: mm::dispatch_fb<mm::HW_FP8>(el_b, shape, opsel, a_regs, b_regs, scale_a, scale_b, out, s); break;
+    }
+    return hipGetLastError() == hipSuccess ? MM_OK : MM_ERR_LAUNCH;
+}
+
+int mm_diag_hw_convert(const void *src_bf16, int n, float scale, int el, uint8_t *out_codes, mm_stream_t stream) {
+    if (n < 0 || (n % 32) || el < 0 || el > 2) return MM_ERR_BAD_ARG;
+    if (n == 0) return MM_OK;
+    const int groups = n / 32;
+    hipLaunchKernelGGL(mm::diag_hw_convert, dim3((groups + 63) / 64), dim3(64), 0, (hipStream_t)stream,
+                       (const uint16_t *)src_bf16, groups, scale, el, out_codes);
+    return hipGetLastError() == hipSuccess ? MM_OK : MM_ERR_LAUNCH;
+}
+}

@@ -1,0 +1,90 @@
+// Device-side helpers shared by the gfx950 kernels: MX element encoders, UE8M0
+// block-scale rule and the scale-factor tensor layout.
+//
+// Semantics restate (not copy) the MicroMix reference:
+//   element formats / maxima   mgemm/src/reorder.cu:17-19, include/reorder.cuh:37-41
+//   scale rule                 mgemm/src/reorder.cu:175-209   (e = ceil(log2(amax/FMAX)))
+//   SF layout                  mgemm/include/sm120_sf_layout.h:170-173
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mm {
+
+// Hardware format codes of v_mfma_scale_f32_*_f8f6f4 (cbsz / blgp fields).
+enum : int { HW_FP8 = 0, HW_BF8 = 1, HW_FP6 = 2, HW_BF6 = 3, HW_FP4 = 4 };
+// Element kinds used by this library (the reference's "FP6" is E3M2 = hardware BF6).
+enum : int { EL_FP4 = 0, EL_FP6 = 1, EL_FP8 = 2 };
+
+template <int EL> struct ElemTraits;
+template <> struct ElemTraits<EL_FP4> {
+    static constexpr int EB = 2, MB = 1, BIAS = 1, MAXCODE = 0x7, HW = HW_FP4;
+    static constexpr int GROUP_BYTES = 16;            // 32 elements
+    static constexpr uint32_t FMAX_MANT = 0x400000;   // 6  = 1.5  * 2^2
+    static constexpr int FMAX_EXP = 2;
+};
+template <> struct ElemTraits<EL_FP6> {
+    static constexpr int EB = 3, MB = 2, BIAS = 3, MAXCODE = 0x1F, HW = HW_BF6;
+    static constexpr int GROUP_BYTES = 24;
+    static constexpr uint32_t FMAX_MANT = 0x600000;   // 28 = 1.75 * 2^4
+    static constexpr int FMAX_EXP = 4;
+};
+template <> struct ElemTraits<EL_FP8> {
+    static constexpr int EB = 4, MB = 3, BIAS = 7, MAXCODE = 0x7E, HW = HW_FP8;
+    static constexpr int GROUP_BYTES = 32;
+    static constexpr uint32_t FMAX_MANT = 0x600000;   // 448 = 1.75 * 2^8
+    static constexpr int FMAX_EXP = 8;
+};
+
+// Smallest e with FMAX * 2^e >= amax (amax given as the fp32 bit pattern of a
+// non-negative bf16 value); zero block -> -1 (scale 0.5, SF byte 126);
+// clamped to [-127, 127] so that e + 127 is a valid UE8M0 byte.
+template <int EL>
+__device__ __forceinline__ int scale_exponent(uint32_t amax_bits) {
+    using T = ElemTraits<EL>;
+    const int exp = (int)(amax_bits >> 23);
+    const uint32_t mant = amax_bits & 0x7FFFFFu;
+    int e = exp - 127 - T::FMAX_EXP + (mant > T::FMAX_MANT ? 1 : 0);
+    e = exp == 0 ? -127 : e;
+    e = e < -127 ? -127 : (e > 127 ? 127 : e);
+    return amax_bits == 0 ? -1 : e;
+}
+
+// fp32 -> element code, round-to-nearest-even, saturating, sign kept on zero.
+template <int EL>
+__device__ __forceinline__ uint32_t encode(float x) {
+    using T = ElemTraits<EL>;
+    constexpr int EMIN = 1 - T::BIAS;
+    constexpr int SHIFT = 23 - T::MB;
+    const uint32_t u = __float_as_uint(x);
+    const uint32_t sign = u >> 31;
+    const uint32_t a = u & 0x7FFFFFFFu;
+    // target-subnormal range: RNE by a magic fp32 add whose ulp is the subnormal quantum
+    constexpr uint32_t MAGIC = (uint32_t)(127 + EMIN - T::MB + 23) << 23;
+    const uint32_t code_s = __float_as_uint(__uint_as_float(a) + __uint_as_float(MAGIC)) - MAGIC;
+    // target-normal range
+    const uint32_t r = a + ((1u << (SHIFT - 1)) - 1u) + ((a >> SHIFT) & 1u);
+    const uint32_t code_n = (r >> SHIFT) - ((uint32_t)(127 - T::BIAS) << T::MB);
+    uint32_t code = a < ((uint32_t)(127 + EMIN) << 23) ? code_s : code_n;
+    code = code > (uint32_t)T::MAXCODE ? (uint32_t)T::MAXCODE : code;
+    return code | (sign << (T::EB + T::MB));
+}
+
+// Byte offset of the scale of (row r, 32-block j) inside one segment of kseg columns.
+__host__ __device__ __forceinline__ size_t sf_offset(int r, int j, int kseg) {
+    return (size_t)(r >> 7) * (size_t)(kseg >> 7) * 512u + (size_t)(j >> 2) * 512u + (size_t)(r & 31) * 16u +
+           (size_t)((r >> 5) & 3) * 4u + (size_t)(j & 3);
+}
+
+__device__ __forceinline__ float bf16_bits_to_f32(uint32_t b) { return __uint_as_float(b << 16); }
+
+// fp32 -> bf16 bits, RNE.  Finite inputs only on the paths that use it (accumulators); a NaN
+// accumulator stays a NaN through the quiet-bit branch.
+__device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) {
+    uint32_t u = __float_as_uint(f);
+    const uint32_t r = (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+    const bool nan = (u & 0x7FFFFFFFu) > 0x7F800000u;
+    return nan ? ((u >> 16) | 0x40u) : r;
+}
+
+}  // namespace mm

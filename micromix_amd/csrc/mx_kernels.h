@@ -1,0 +1,27 @@
+// Host-side launch interface between capi.hip and the kernel translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mm {
+
+struct GemmArgs {
+    const uint8_t *X[3];    // activation segments  (AN, AS, AO)
+    const uint8_t *W[3];    // weight segments      (BN, BS, BO)
+    const uint8_t *SFX[3];  // activation scales
+    const uint8_t *SFW[3];  // weight scales
+    int K[3];
+    int M, N;
+    int sfx_row_tiles;      // allocated 128-row tiles in the activation SF tensors
+    int sfw_row_tiles;
+    int round_per_segment;
+    const uint16_t *bias;   // optional [N] bf16
+    uint16_t *D;            // [M, N] bf16
+};
+
+hipError_t launch_reorder_quantize(const void *src, int rows, int K, const int16_t *idx, int KN, int KS, int KO, bool w4,
+                                   uint8_t *oN, uint8_t *oS, uint8_t *oO, uint8_t *sfN, uint8_t *sfS, uint8_t *sfO,
+                                   hipStream_t stream);
+hipError_t launch_mx_gemm(const GemmArgs &a, bool w4, hipStream_t stream);
+
+}  // namespace mm

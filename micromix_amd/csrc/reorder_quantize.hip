@@ -1,0 +1,184 @@
+// Fused column-reorder + per-32-group absmax + UE8M0 scale + MXFP4/MXFP6/MXFP8
+// quantize + pack for gfx950.
+//
+// What it computes is the reference's reorder_quantize_mixed_kernel
+// (mgemm/src/reorder.cu:94-269) and reorder_quantize_mxfp4_kernel (:271-432):
+// for every row and every 32-wide group g of *reordered* columns,
+//   v[i] = row[idx[32g+i]];  amax = max|v|;  e = ceil(log2(amax/FMAX)) (amax==0 -> -1);
+//   q[i] = RNE_fmt(v[i] * 2^-e);  SF byte = e + 127 at sf_offset(row, g - seg_start/32).
+//
+// How it is laid out for MI355X (HBM-bound: 2*K bytes in, ~K/2..K bytes out per row):
+//  * one workgroup owns a strided set of rows; thread t owns group t for every one
+//    of those rows, so its 32 reorder indices live in 16 VGPRs for the whole launch
+//    (the reference re-reads each index from global memory per element);
+//  * the row is staged in LDS with 16-byte coalesced loads; the next row's loads are
+//    issued before the current row's gather so HBM latency hides under the LDS work;
+//  * all scale arithmetic is integer/exponent arithmetic (no log2/ceil/ldexp/divide).
+#include "mx_common.h"
+#include "mx_kernels.h"
+
+namespace mm {
+
+template <int EL>
+__device__ __forceinline__ void quantize_group(const uint16_t *__restrict__ row, const uint32_t (&ix)[16],
+                                               uint8_t *__restrict__ out, uint8_t *__restrict__ sf) {
+    uint32_t v[32];
+    uint32_t amax = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const uint32_t a = row[ix[i] & 0xFFFFu];
+        const uint32_t b = row[ix[i] >> 16];
+        v[2 * i] = a;
+        v[2 * i + 1] = b;
+        const uint32_t ma = a & 0x7FFFu, mb = b & 0x7FFFu;
+        amax = amax > ma ? amax : ma;
+        amax = amax > mb ? amax : mb;
+    }
+    const int e = scale_exponent<EL>(amax << 16);
+    *sf = (uint8_t)(e + 127);
+    // 2^-e as fp32.  e <= 126 for any finite bf16 amax (bf16 max / 6 < 2^126), so 127 - e >= 1 is a
+    // normal exponent field; e >= -127 gives at most 254.
+    const float rs = __uint_as_float((uint32_t)(127 - e) << 23);
+
+    uint32_t c[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) c[i] = encode<EL>(bf16_bits_to_f32(v[i]) * rs);
+
+    if constexpr (EL == EL_FP8) {
+        uint32_t w[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) w[i] = c[4 * i] | (c[4 * i + 1] << 8) | (c[4 * i + 2] << 16) | (c[4 * i + 3] << 24);
+        uint4 *o = reinterpret_cast<uint4 *>(out);
+        o[0] = make_uint4(w[0], w[1], w[2], w[3]);
+        o[1] = make_uint4(w[4], w[5], w[6], w[7]);
+    } else if constexpr (EL == EL_FP4) {
+        uint32_t w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            uint32_t x = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) x |= (c[8 * i + k] & 0xFu) << (4 * k);  // element 2i in the low nibble
+            w[i] = x;
+        }
+        *reinterpret_cast<uint4 *>(out) = make_uint4(w[0], w[1], w[2], w[3]);
+    } else {
+        // dense little-endian 6-bit stream: 32 codes -> 192 bits -> three 64-bit words
+        unsigned long long w[3] = {0ull, 0ull, 0ull};
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const int bit = 6 * i, word = bit >> 6, off = bit & 63;
+            const unsigned long long code = c[i] & 0x3Fu;
+            w[word] |= code << off;
+            if (off > 58) w[word + 1] |= code >> (64 - off);
+        }
+        unsigned long long *o = reinterpret_cast<unsigned long long *>(out);
+        o[0] = w[0];
+        o[1] = w[1];
+        o[2] = w[2];
+    }
+}
+
+template <bool W4, int MAXT>
+__global__ void __launch_bounds__(MAXT)
+reorder_quantize_kernel(const uint16_t *__restrict__ src, int rows, int K, const int16_t *__restrict__ idx, int KN,
+                        int KS, int KO, uint8_t *__restrict__ oN, uint8_t *__restrict__ oS, uint8_t *__restrict__ oO,
+                        uint8_t *__restrict__ sfN, uint8_t *__restrict__ sfS, uint8_t *__restrict__ sfO) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int G = K >> 5;
+    const int g = threadIdx.x;
+    const bool active = g < G;
+    const int nchunk = K >> 3;  // 16-byte chunks per row
+
+    uint32_t ix[16];
+    if (active) {
+        const uint4 *p = reinterpret_cast<const uint4 *>(idx + (size_t)g * 32);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint4 q = p[i];
+            ix[4 * i] = q.x;
+            ix[4 * i + 1] = q.y;
+            ix[4 * i + 2] = q.z;
+            ix[4 * i + 3] = q.w;
+        }
+    }
+    // Which segment this thread's group falls in (positions in reordered order).
+    const int gN = KN >> 5, gS = KS >> 5;
+    int seg, j, kseg;
+    if (g < gN) { seg = 0; j = g; kseg = KN; }
+    else if (g < gN + gS) { seg = 1; j = g - gN; kseg = KS; }
+    else { seg = 2; j = g - gN - gS; kseg = KO; }
+
+    uint4 stage[4];
+    int r = blockIdx.x;
+    if (r < rows) {
+        const uint4 *grow = reinterpret_cast<const uint4 *>(src + (size_t)r * K);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = threadIdx.x + i * blockDim.x;
+            uint4 t = make_uint4(0u, 0u, 0u, 0u);
+            if (c < nchunk) t = grow[c];
+            stage[i] = t;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = threadIdx.x + i * blockDim.x;
+            if (c < nchunk) reinterpret_cast<uint4 *>(smem)[c] = stage[i];
+        }
+    }
+    __syncthreads();
+    for (; r < rows; r += gridDim.x) {
+        const int rn = r + gridDim.x;
+        if (rn < rows) {
+            const uint4 *grow = reinterpret_cast<const uint4 *>(src + (size_t)rn * K);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int c = threadIdx.x + i * blockDim.x;
+                uint4 t = make_uint4(0u, 0u, 0u, 0u);
+                if (c < nchunk) t = grow[c];
+                stage[i] = t;
+            }
+        }
+        if (active) {
+            const uint16_t *row = reinterpret_cast<const uint16_t *>(smem);
+            if (seg == 0) {
+                quantize_group<EL_FP4>(row, ix, oN + (size_t)r * (KN >> 1) + j * 16, sfN + sf_offset(r, j, kseg));
+            } else if (seg == 1) {
+                if constexpr (W4)
+                    quantize_group<EL_FP4>(row, ix, oS + (size_t)r * (KS >> 1) + j * 16, sfS + sf_offset(r, j, kseg));
+                else
+                    quantize_group<EL_FP6>(row, ix, oS + (size_t)r * (KS / 4 * 3) + j * 24, sfS + sf_offset(r, j, kseg));
+            } else {
+                if constexpr (W4)
+                    quantize_group<EL_FP4>(row, ix, oO + (size_t)r * (KO >> 1) + j * 16, sfO + sf_offset(r, j, kseg));
+                else
+                    quantize_group<EL_FP8>(row, ix, oO + (size_t)r * KO + j * 32, sfO + sf_offset(r, j, kseg));
+            }
+        }
+        __syncthreads();
+        if (rn < rows) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int c = threadIdx.x + i * blockDim.x;
+                if (c < nchunk) reinterpret_cast<uint4 *>(smem)[c] = stage[i];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+hipError_t launch_reorder_quantize(const void *src, int rows, int K, const int16_t *idx, int KN, int KS, int KO, bool w4,
+                                   uint8_t *oN, uint8_t *oS, uint8_t *oO, uint8_t *sfN, uint8_t *sfS, uint8_t *sfO,
+                                   hipStream_t stream) {
+    if (rows == 0) return hipSuccess;
+    const int G = K / 32;
+    const int threads = (G + 63) / 64 * 64;
+    const size_t lds = (size_t)K * 2;
+    int blocks = rows < 256 * 8 ? rows : 256 * 8;
+    auto kern = threads <= 256 ? (w4 ? reorder_quantize_kernel<true, 256> : reorder_quantize_kernel<false, 256>)
+                               : (w4 ? reorder_quantize_kernel<true, 1024> : reorder_quantize_kernel<false, 1024>);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds, stream, (const uint16_t *)src, rows, K, idx, KN, KS, KO, oN,
+                       oS, oO, sfN, sfS, sfO);
+    return hipGetLastError();
+}
+
+}  // namespace mm

@@ -1,0 +1,157 @@
+"""`mixedgemm` -- drop-in for the reference's pybind11 extension of the same name
+(mgemm/src/bindings.cpp:682-742), MX hot path only, backed by libmicromix_hip.so.
+
+Same function names, argument order, keyword names, return tuples, dtypes and shapes:
+
+    matmul(AN, BN, AS, BS, AO, BO, SFAN, SFBN, SFAS, SFBS, SFAO, SFBO) -> Tensor[M, N] bf16
+    reorder_quantize_x(X, reorder_index, KN, KS, KO)  -> (XN, XS, XO, SFXN, SFXS, SFXO)
+    reorder_quantize_w(W, reorder_index, KN, KS, KO)  -> (WN, WS, WO, SFWN, SFWS, SFWO)
+    reorder_quantize_w4(W, reorder_index, KN, KS, KO) -> (WN, WS, WO, SFWN, SFWS, SFWO)
+
+Differences from the reference, all deliberate:
+  * kernels are queued on torch's CURRENT stream of the tensors' device (the reference uses
+    the legacy default stream and no device guard, reorder.cu:455, w4a4.cu:182);
+  * any K that is a multiple of 128 (<= 32768) works, not only the ten compiled-in values
+    (bindings.cpp:134-148); bad splits still raise RuntimeError("Value error in run_...");
+  * inputs are validated (dtype/device/contiguity) instead of being reinterpreted blindly;
+  * `matmul` takes optional keyword-only `bias` and `rounding` arguments (extensions).
+The remaining exports of the reference module (rmsnorm_quantize_x, activate_quantize_x,
+downproj_quantize_w/_w4, FlashInfer KV ops) are outside the hot path; they raise
+NotImplementedError.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+
+__all__ = ["matmul", "reorder_quantize_x", "reorder_quantize_w", "reorder_quantize_w4"]
+
+
+def _stream_ptr(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _check_tensor(t, name, dtype, device=None):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if t.dtype != dtype:
+        raise TypeError(f"{name} must be {dtype}, got {t.dtype}")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a device tensor (HIP); the MicroMix ops have no CPU path")
+    if device is not None and t.device != device:
+        raise RuntimeError(f"{name} is on {t.device}, expected {device}")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous")
+
+
+def _ptr(t):
+    return t.data_ptr() if t.numel() else None
+
+
+def _quantize(src, reorder_index, KN, KS, KO, mode, what):
+    lib = _lib.load()
+    _check_tensor(src, "X" if mode == "x" else "W", torch.bfloat16)
+    _check_tensor(reorder_index, "reorder_index", torch.int16, src.device)
+    if src.dim() != 2:
+        raise RuntimeError("input must be 2-D [rows, K]")
+    KN, KS, KO = int(KN), int(KS), int(KO)
+    rows, K = src.shape
+    if reorder_index.numel() != K:
+        _lib.check(_lib.MM_ERR_BAD_SPLIT, what)
+    if KN < 0 or KS < 0 or KO < 0 or KN + KS + KO != K or KN % 128 or KS % 128 or KO % 128:
+        _lib.check(_lib.MM_ERR_BAD_SPLIT, what)
+    opt = dict(dtype=torch.uint8, device=src.device)
+    w4 = mode == "w4"
+    oN = torch.empty((rows, KN // 2), **opt)
+    oS = torch.empty((rows, KS // 2 if w4 else KS // 4 * 3), **opt)
+    oO = torch.empty((rows, KO // 2 if w4 else KO), **opt)
+    sf_bytes = lib.mm_sf_bytes_x if mode == "x" else lib.mm_sf_bytes_w
+    sfN = torch.empty((sf_bytes(rows, KN),), **opt)
+    sfS = torch.empty((sf_bytes(rows, KS),), **opt)
+    sfO = torch.empty((sf_bytes(rows, KO),), **opt)
+    with torch.cuda.device(src.device):
+        st = lib.mm_reorder_quantize(
+            _ptr(src), rows, K, _ptr(reorder_index), KN, KS, KO,
+            _lib.MM_QUANT_W4 if w4 else _lib.MM_QUANT_MIXED,
+            _ptr(oN), _ptr(oS), _ptr(oO), _ptr(sfN), _ptr(sfS), _ptr(sfO), _stream_ptr(src.device))
+    _lib.check(st, what)
+    return oN, oS, oO, sfN, sfS, sfO
+
+
+def reorder_quantize_x(X, reorder_index, KN, KS, KO):
+    """bindings.cpp:104-151.  X [M,K] bf16 -> XN [M,KN/2], XS [M,3KS/4], XO [M,KO] + 3 SF tensors."""
+    return _quantize(X, reorder_index, KN, KS, KO, "x", "reorder_quantize_x")
+
+
+def reorder_quantize_w(W, reorder_index, KN, KS, KO):
+    """bindings.cpp:155-202.  W [N,K] bf16 -> WN [N,KN/2], WS [N,3KS/4], WO [N,KO] + 3 SF tensors."""
+    return _quantize(W, reorder_index, KN, KS, KO, "w", "reorder_quantize_w")
+
+
+def reorder_quantize_w4(W, reorder_index, KN, KS, KO):
+    """bindings.cpp:206-253.  W [N,K] bf16 -> WN [N,KN/2], WS [N,KS/2], WO [N,KO/2] + 3 SF tensors."""
+    return _quantize(W, reorder_index, KN, KS, KO, "w4", "reorder_quantize_w4")
+
+
+def matmul(AN, BN, AS, BS, AO, BO, SFAN, SFBN, SFAS, SFBS, SFAO, SFBO, *, bias=None, rounding="reference", out=None):
+    """bindings.cpp:50-102.  Returns a new [M, N] bf16 tensor.
+
+    Shapes are derived exactly as the reference does (bindings.cpp:66-70) and the weight mode
+    from `AS.size(1) == BS.size(1) and AO.size(1) == BO.size(1)` (bindings.cpp:74,87).
+    """
+    lib = _lib.load()
+    dev = AN.device
+    names = ("AN", "BN", "AS", "BS", "AO", "BO", "SFAN", "SFBN", "SFAS", "SFBS", "SFAO", "SFBO")
+    tensors = (AN, BN, AS, BS, AO, BO, SFAN, SFBN, SFAS, SFBS, SFAO, SFBO)
+    for n, t in zip(names, tensors):
+        _check_tensor(t, n, torch.uint8, dev)
+    M, N = AN.size(0), BN.size(0)
+    KN, KS, KO = AN.size(1) * 2, AS.size(1) * 4 // 3, AO.size(1)
+    same = AS.size(1) == BS.size(1) and AO.size(1) == BO.size(1)
+    wmode = _lib.MM_W_MATCH if same else _lib.MM_W_FP4
+    exp_b = (KN // 2, KS // 4 * 3 if same else KS // 2, KO if same else KO // 2)
+    for n, t, w in zip(("BN", "BS", "BO"), (BN, BS, BO), exp_b):
+        if t.dim() != 2 or t.size(0) != N or t.size(1) != w:
+            raise RuntimeError(f"{n} has shape {tuple(t.shape)}, expected ({N}, {w})")
+    for n, t in zip(("AS", "AO"), (AS, AO)):
+        if t.dim() != 2 or t.size(0) != M:
+            raise RuntimeError(f"{n} must be [M, bytes]")
+    for n, t, rows_bytes in (("SFAN", SFAN, lib.mm_sf_bytes_w(M, KN)), ("SFAS", SFAS, lib.mm_sf_bytes_w(M, KS)),
+                             ("SFAO", SFAO, lib.mm_sf_bytes_w(M, KO)), ("SFBN", SFBN, lib.mm_sf_bytes_w(N, KN)),
+                             ("SFBS", SFBS, lib.mm_sf_bytes_w(N, KS)), ("SFBO", SFBO, lib.mm_sf_bytes_w(N, KO))):
+        if t.numel() < rows_bytes:
+            raise RuntimeError(f"{n} holds {t.numel()} scale bytes, needs at least {rows_bytes}")
+    if rounding not in ("reference", "fused"):
+        raise ValueError("rounding must be 'reference' or 'fused'")
+    flags = _lib.MM_ROUND_PER_SEGMENT if rounding == "reference" else _lib.MM_ROUND_ONCE
+    if bias is not None:
+        _check_tensor(bias, "bias", torch.bfloat16, dev)
+        if bias.numel() != N:
+            raise RuntimeError("bias must have N elements")
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+    else:
+        _check_tensor(out, "out", torch.bfloat16, dev)
+        if tuple(out.shape) != (M, N):
+            raise RuntimeError("out has the wrong shape")
+    with torch.cuda.device(dev):
+        st = lib.mm_matmul(*[_ptr(t) for t in tensors], M, N, KN, KS, KO, wmode, flags,
+                           _ptr(bias) if bias is not None else None, _ptr(out), _stream_ptr(dev))
+    _lib.check(st, "matmul")
+    return out
+
+
+def _not_on_path(name):
+    def f(*a, **k):
+        raise NotImplementedError(f"mixedgemm.{name} is outside the MX hot path built here (SURVEY.md section 8f)")
+    f.__name__ = name
+    return f
+
+
+rmsnorm_quantize_x = _not_on_path("rmsnorm_quantize_x")
+activate_quantize_x = _not_on_path("activate_quantize_x")
+downproj_quantize_w = _not_on_path("downproj_quantize_w")
+downproj_quantize_w4 = _not_on_path("downproj_quantize_w4")
+for _n in ("batch_decode_i4", "batch_decode_f16", "init_kv_i4", "init_kv_f16", "append_kv_i4", "append_kv_f16"):
+    globals()[_n] = _not_on_path(_n)
