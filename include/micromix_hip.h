@@ -86,6 +86,16 @@ int mm_reorder_quantize(const void *src_bf16, int rows, int K, const int16_t *re
                         mm_stream_t stream);
 
 /*
+ * Same kernel, gathering only a SUBSET of the input columns: `index` has KN+KS+KO (<= K_in) entries, each
+ * < K_in, and the rows of src are K_in wide.  This is what a K-sharded (row-parallel) tensor-parallel rank
+ * runs: it quantizes just its 128-aligned slices of the reordered segments (micromix_amd/tp.py).  No
+ * counterpart in the reference, which has no tensor parallelism.
+ */
+int mm_reorder_quantize_gather(const void *src_bf16, int rows, int K_in, const int16_t *index, int KN, int KS, int KO,
+                               int mode, uint8_t *oN, uint8_t *oS, uint8_t *oO, uint8_t *sfN, uint8_t *sfS, uint8_t *sfO,
+                               mm_stream_t stream);
+
+/*
  * Three-segment mixed-precision block-scaled GEMM:
  *   D[m,n] = bf16( sum over segments, blocks b:  2^(sfa[m,b]-127) * 2^(sfb[n,b]-127) * sum_{k in b} a[m,k]*b[n,k] ) (+ bias[n])
  *   A segments: AN [M,KN/2] fp4, AS [M,3KS/4] fp6(E3M2), AO [M,KO] fp8(E4M3)
@@ -111,6 +121,10 @@ int mm_matmul(const uint8_t *AN, const uint8_t *BN, const uint8_t *AS, const uin
 int mm_diag_mfma(int shape, int el_a, int el_b, int opsel, const void *a_regs, const void *b_regs, const void *scale_a,
                  const void *scale_b, void *out, mm_stream_t stream);
 int mm_diag_hw_convert(const void *src_bf16, int n, float scale, int el, uint8_t *out_codes, mm_stream_t stream);
+/* Issue-rate microbenchmark: `blocks` workgroups of 4 waves, each wave issues iters*8 independent scaled
+ * MFMAs on register operands taken from seed_regs ([128][8] int32).  flops = blocks*4*iters*8*2*M*N*K. */
+int mm_diag_mfma_rate(int shape, int el_a, int el_b, int blocks, int iters, const void *seed_regs, void *sink,
+                      mm_stream_t stream);
 
 #ifdef __cplusplus
 }

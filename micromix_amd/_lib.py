@@ -15,8 +15,8 @@ LIB_PATH = os.path.join(_PKG, "lib", "libmicromix_hip.so")
 EXPORTS = (
     "mm_version", "mm_strerror", "mm_last_error",
     "mm_sf_bytes_x", "mm_sf_bytes_w", "mm_sf_offset",
-    "mm_reorder_quantize", "mm_matmul",
-    "mm_diag_mfma", "mm_diag_hw_convert",
+    "mm_reorder_quantize", "mm_reorder_quantize_gather", "mm_matmul",
+    "mm_diag_mfma", "mm_diag_hw_convert", "mm_diag_mfma_rate",
 )
 
 MM_OK, MM_ERR_BAD_SPLIT, MM_ERR_BAD_ARG, MM_ERR_LAUNCH, MM_ERR_UNSUPPORTED, MM_ERR_NO_DEVICE = range(6)
@@ -56,12 +56,16 @@ def load():
     lib.mm_sf_offset.argtypes = [i, i, i]
     lib.mm_reorder_quantize.restype = i
     lib.mm_reorder_quantize.argtypes = [vp, i, i, vp, i, i, i, i, vp, vp, vp, vp, vp, vp, vp]
+    lib.mm_reorder_quantize_gather.restype = i
+    lib.mm_reorder_quantize_gather.argtypes = [vp, i, i, vp, i, i, i, i, vp, vp, vp, vp, vp, vp, vp]
     lib.mm_matmul.restype = i
     lib.mm_matmul.argtypes = [vp] * 12 + [i] * 7 + [vp, vp, vp]
     lib.mm_diag_mfma.restype = i
     lib.mm_diag_mfma.argtypes = [i, i, i, i, vp, vp, vp, vp, vp, vp]
     lib.mm_diag_hw_convert.restype = i
     lib.mm_diag_hw_convert.argtypes = [vp, i, ctypes.c_float, i, vp, vp]
+    lib.mm_diag_mfma_rate.restype = i
+    lib.mm_diag_mfma_rate.argtypes = [i, i, i, i, i, vp, vp, vp]
     _lib = lib
     return lib
 

@@ -54,6 +54,19 @@ int mm_reorder_quantize(const void *src_bf16, int rows, int K, const int16_t *re
     return e == hipSuccess ? MM_OK : fail_hip(e, "mm_reorder_quantize");
 }
 
+int mm_reorder_quantize_gather(const void *src_bf16, int rows, int K_in, const int16_t *index, int KN, int KS, int KO,
+                               int mode, uint8_t *oN, uint8_t *oS, uint8_t *oO, uint8_t *sfN, uint8_t *sfS, uint8_t *sfO,
+                               mm_stream_t stream) {
+    if (!split_ok(KN + KS + KO, KN, KS, KO) || K_in <= 0 || (K_in % 128) || KN + KS + KO > K_in) return MM_ERR_BAD_SPLIT;
+    if (rows < 0 || K_in > 32768 || (mode != MM_QUANT_MIXED && mode != MM_QUANT_W4)) return MM_ERR_BAD_ARG;
+    if (rows == 0) return MM_OK;
+    if (!src_bf16 || !index) return MM_ERR_BAD_ARG;
+    if ((KN && (!oN || !sfN)) || (KS && (!oS || !sfS)) || (KO && (!oO || !sfO))) return MM_ERR_BAD_ARG;
+    hipError_t e = mm::launch_reorder_quantize(src_bf16, rows, K_in, index, KN, KS, KO, mode == MM_QUANT_W4, oN, oS, oO,
+                                               sfN, sfS, sfO, (hipStream_t)stream);
+    return e == hipSuccess ? MM_OK : fail_hip(e, "mm_reorder_quantize_gather");
+}
+
 int mm_matmul(const uint8_t *AN, const uint8_t *BN, const uint8_t *AS, const uint8_t *BS, const uint8_t *AO,
               const uint8_t *BO, const uint8_t *SFAN, const uint8_t *SFBN, const uint8_t *SFAS, const uint8_t *SFBS,
               const uint8_t *SFAO, const uint8_t *SFBO, int M, int N, int KN, int KS, int KO, int wmode, int flags,

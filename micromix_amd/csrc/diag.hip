@@ -114,9 +114,76 @@ __global__ void diag_hw_convert(const uint16_t *src, int ngroups, float scale, i
     }
 }
 
+// Register-only issue-rate loop: every wave issues `iters` x 8 independent scaled MFMAs.
+template <int FA, int FB, int SHAPE>
+__global__ void __launch_bounds__(256) diag_mfma_rate(const v8i *seed, int iters, float *sink) {
+    const int l = threadIdx.x & 63;
+    v8i a = seed[l], b = seed[64 + l];
+    const int sa = 127, sb = 127;
+    if constexpr (SHAPE == 32) {
+        v16f acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[j][i] = 0.0f;
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                acc[j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, acc[j], FA, FB, 0, sa, 0, sb);
+        }
+        float t = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t += acc[j][0] + acc[j][15];
+        if (t == 12345.678f) sink[0] = t;
+    } else {
+        v4f acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                acc[j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, acc[j], FA, FB, 0, sa, 0, sb);
+        }
+        float t = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t += acc[j][0] + acc[j][3];
+        if (t == 12345.678f) sink[0] = t;
+    }
+}
+
+template <int FA, int FB>
+static void launch_rate(int shape, int blocks, const void *seed, int iters, float *sink, hipStream_t s) {
+    if (shape == 32)
+        hipLaunchKernelGGL((diag_mfma_rate<FA, FB, 32>), dim3(blocks), dim3(256), 0, s, (const v8i *)seed, iters, sink);
+    else
+        hipLaunchKernelGGL((diag_mfma_rate<FA, FB, 16>), dim3(blocks), dim3(256), 0, s, (const v8i *)seed, iters, sink);
+}
+
+template <int FA>
+static void rate_fb(int fb, int shape, int blocks, const void *seed, int iters, float *sink, hipStream_t s) {
+    switch (fb) {
+        case EL_FP4: launch_rate<FA, HW_FP4>(shape, blocks, seed, iters, sink, s); break;
+        case EL_FP6: launch_rate<FA, HW_BF6>(shape, blocks, seed, iters, sink, s); break;
+        default: launch_rate<FA, HW_FP8>(shape, blocks, seed, iters, sink, s); break;
+    }
+}
+
 }  // namespace mm
 
 extern "C" {
+
+int mm_diag_mfma_rate(int shape, int el_a, int el_b, int blocks, int iters, const void *seed_regs, void *sink,
+                      mm_stream_t stream) {
+    if ((shape != 32 && shape != 16) || el_a < 0 || el_a > 2 || el_b < 0 || el_b > 2 || blocks <= 0 || iters <= 0)
+        return MM_ERR_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    switch (el_a) {
+        case mm::EL_FP4: mm::rate_fb<mm::HW_FP4>(el_b, shape, blocks, seed_regs, iters, (float *)sink, s); break;
+        case mm::EL_FP6: mm::rate_fb<mm::HW_BF6>(el_b, shape, blocks, seed_regs, iters, (float *)sink, s); break;
+        default: mm::rate_fb<mm::HW_FP8>(el_b, shape, blocks, seed_regs, iters, (float *)sink, s); break;
+    }
+    return hipGetLastError() == hipSuccess ? MM_OK : MM_ERR_LAUNCH;
+}
 
 int mm_diag_mfma(int shape, int el_a, int el_b, int opsel, const void *a_regs, const void *b_regs, const void *scale_a,
                  const void *scale_b, void *out, mm_stream_t stream) {

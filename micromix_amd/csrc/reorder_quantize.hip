@@ -84,7 +84,7 @@ reorder_quantize_kernel(const uint16_t *__restrict__ src, int rows, int K, const
                         int KS, int KO, uint8_t *__restrict__ oN, uint8_t *__restrict__ oS, uint8_t *__restrict__ oO,
                         uint8_t *__restrict__ sfN, uint8_t *__restrict__ sfS, uint8_t *__restrict__ sfO) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const int G = K >> 5;
+    const int G = (KN + KS + KO) >> 5;  // groups produced; K is the input row length (>= 32 * G)
     const int g = threadIdx.x;
     const bool active = g < G;
     const int nchunk = K >> 3;  // 16-byte chunks per row
@@ -170,8 +170,9 @@ hipError_t launch_reorder_quantize(const void *src, int rows, int K, const int16
                                    uint8_t *oN, uint8_t *oS, uint8_t *oO, uint8_t *sfN, uint8_t *sfS, uint8_t *sfO,
                                    hipStream_t stream) {
     if (rows == 0) return hipSuccess;
-    const int G = K / 32;
-    const int threads = (G + 63) / 64 * 64;
+    const int G = (KN + KS + KO) / 32;
+    const int stagers = K / 32;  // a row of K bf16 is staged as K/8 16-byte chunks, at most 4 per thread
+    const int threads = ((G > stagers ? G : stagers) + 63) / 64 * 64;
     const size_t lds = (size_t)K * 2;
     int blocks = rows < 256 * 8 ? rows : 256 * 8;
     auto kern = threads <= 256 ? (w4 ? reorder_quantize_kernel<true, 256> : reorder_quantize_kernel<false, 256>)

@@ -49,7 +49,7 @@ def _ptr(t):
     return t.data_ptr() if t.numel() else None
 
 
-def _quantize(src, reorder_index, KN, KS, KO, mode, what):
+def _quantize(src, reorder_index, KN, KS, KO, mode, what, gather_subset=False):
     lib = _lib.load()
     _check_tensor(src, "X" if mode == "x" else "W", torch.bfloat16)
     _check_tensor(reorder_index, "reorder_index", torch.int16, src.device)
@@ -57,9 +57,11 @@ def _quantize(src, reorder_index, KN, KS, KO, mode, what):
         raise RuntimeError("input must be 2-D [rows, K]")
     KN, KS, KO = int(KN), int(KS), int(KO)
     rows, K = src.shape
-    if reorder_index.numel() != K:
+    if reorder_index.numel() != KN + KS + KO:
         _lib.check(_lib.MM_ERR_BAD_SPLIT, what)
-    if KN < 0 or KS < 0 or KO < 0 or KN + KS + KO != K or KN % 128 or KS % 128 or KO % 128:
+    if KN < 0 or KS < 0 or KO < 0 or KN % 128 or KS % 128 or KO % 128 or K % 128:
+        _lib.check(_lib.MM_ERR_BAD_SPLIT, what)
+    if (KN + KS + KO != K) if not gather_subset else (KN + KS + KO > K or KN + KS + KO == 0):
         _lib.check(_lib.MM_ERR_BAD_SPLIT, what)
     opt = dict(dtype=torch.uint8, device=src.device)
     w4 = mode == "w4"
@@ -71,7 +73,8 @@ def _quantize(src, reorder_index, KN, KS, KO, mode, what):
     sfS = torch.empty((sf_bytes(rows, KS),), **opt)
     sfO = torch.empty((sf_bytes(rows, KO),), **opt)
     with torch.cuda.device(src.device):
-        st = lib.mm_reorder_quantize(
+        entry = lib.mm_reorder_quantize_gather if gather_subset else lib.mm_reorder_quantize
+        st = entry(
             _ptr(src), rows, K, _ptr(reorder_index), KN, KS, KO,
             _lib.MM_QUANT_W4 if w4 else _lib.MM_QUANT_MIXED,
             _ptr(oN), _ptr(oS), _ptr(oO), _ptr(sfN), _ptr(sfS), _ptr(sfO), _stream_ptr(src.device))

@@ -1,0 +1,132 @@
+"""Tensor-parallel (row-parallel, K-sharded) QLinear over RCCL -- new design, the reference has no
+collectives at all (BASELINE.json north_star).
+
+Rank g owns, for each of the three reordered segments (MXFP4 | MXFP6 | MXFP8), a 128-column-aligned
+slice of the *reordered* columns.  It
+  1. packs only its slice of the weight once (reorder_quantize_w4 over a sub-index),
+  2. per forward quantizes only its slice of the activation columns (the gather kernel reads the full
+     replicated x row and produces KN_g + KS_g + KO_g columns),
+  3. runs the fused three-segment GEMM on its shard -> partial [M, N] bf16,
+  4. sums the partials with ONE all-reduce on the bf16 output (RCCL over xGMI; `nccl` backend).
+Because MX blocks are 32 columns and shards are 128-aligned, every block keeps exactly the scale it has
+in the unsharded layer: the sharded product is the unsharded one up to the order of the final sums.
+
+Shards are balanced by COST, not width: an fp8-operand column costs ~1.67x an fp4 column on the MFMA
+(measured issue rates, tools/mfma_rate.py), so each rank gets a share of every segment.
+
+The compute backend is injectable (`ops`) so that the partition / reduction logic can be exercised on
+CPU with `gloo` by the tests; the product default is the HIP `mixedgemm` module (no CPU fallback).
+"""
+from __future__ import annotations
+
+from typing import List, Sequence, Tuple
+
+import torch
+
+# relative MFMA cost per column of (fp4, fp6, fp8) activations against fp4 weights (w4 mode)
+SEGMENT_COST = (1.0, 1.07, 1.67)
+
+
+def plan_k_shards(kn: int, ks: int, ko: int, world: int) -> List[Tuple[Tuple[int, int], Tuple[int, int], Tuple[int, int]]]:
+    """Per rank, for each segment, (start, width) in reordered-segment columns; widths are multiples of
+    128, every column is owned exactly once, and each segment is split as evenly as 128-granules allow
+    (the remainder granules of different segments are dealt to different ranks, heaviest segment first,
+    so that the per-rank cost stays balanced)."""
+    if world < 1:
+        raise ValueError("world must be >= 1")
+    for k in (kn, ks, ko):
+        if k < 0 or k % 128:
+            raise ValueError("segment widths must be non-negative multiples of 128")
+    widths = [[0] * 3 for _ in range(world)]
+    load = [0.0] * world
+    order = sorted(range(3), key=lambda s: -SEGMENT_COST[s])
+    for s in order:
+        gran = (kn, ks, ko)[s] // 128
+        base, rem = divmod(gran, world)
+        for r in range(world):
+            widths[r][s] = base * 128
+            load[r] += base * 128 * SEGMENT_COST[s]
+        for _ in range(rem):                      # leftover granules go to the currently lightest ranks
+            r = min(range(world), key=lambda i: (load[i], i))
+            widths[r][s] += 128
+            load[r] += 128 * SEGMENT_COST[s]
+    plan = []
+    starts = [0, 0, 0]
+    for r in range(world):
+        plan.append(tuple((starts[s], widths[r][s]) for s in range(3)))
+        for s in range(3):
+            starts[s] += widths[r][s]
+    return plan
+
+
+def shard_index(reorder_index: torch.Tensor, kn: int, ks: int, ko: int, shard) -> torch.Tensor:
+    """the rank's sub-index: its slice of each segment of the full reorder index, concatenated."""
+    seg_base = (0, kn, kn + ks)
+    parts = [reorder_index[seg_base[s] + shard[s][0]: seg_base[s] + shard[s][0] + shard[s][1]] for s in range(3)]
+    return torch.cat(parts).contiguous()
+
+
+class _HipOps:
+    """default backend: the HIP kernels (micromix_amd.mixedgemm)."""
+
+    @staticmethod
+    def quantize_w4(w, index, kn, ks, ko):
+        from . import mixedgemm
+        return mixedgemm._quantize(w, index, kn, ks, ko, "w4", "reorder_quantize_w4", gather_subset=True)
+
+    @staticmethod
+    def quantize_x(x, index, kn, ks, ko):
+        from . import mixedgemm
+        return mixedgemm._quantize(x, index, kn, ks, ko, "x", "reorder_quantize_x", gather_subset=True)
+
+    @staticmethod
+    def matmul(a, b, out=None):
+        from . import mixedgemm
+        return mixedgemm.matmul(a[0], b[0], a[1], b[1], a[2], b[2], a[3], b[3], a[4], b[4], a[5], b[5], out=out)
+
+
+class TPShardedLinear:
+    """One QLinear, K-sharded over `world` ranks.  w [N, K] bf16 and reorder_index [K] int16 are the FULL
+    tensors (each rank slices its own part); x passed to forward is the full replicated [M, K] activation."""
+
+    def __init__(self, w: torch.Tensor, reorder_index: torch.Tensor, p4: int, p6: int, p8: int, rank: int, world: int,
+                 group=None, ops=None, bias: torch.Tensor | None = None):
+        self.rank, self.world, self.group = rank, world, group
+        self.ops = ops if ops is not None else _HipOps
+        self.N, self.K = w.shape
+        if p4 + p6 + p8 != self.K:
+            raise ValueError("p4 + p6 + p8 must equal in_features")
+        self.plan = plan_k_shards(p4, p6, p8, world)
+        self.shard = self.plan[rank]
+        self.shard_widths = [s[1] for s in self.shard]
+        self.index = shard_index(reorder_index, p4, p6, p8, self.shard)
+        self.empty = sum(self.shard_widths) == 0
+        self.bias = bias
+        if not self.empty:
+            self.packed_w = self.ops.quantize_w4(w, self.index, *self.shard_widths)
+
+    def quantize_x(self, x: torch.Tensor):
+        return None if self.empty else self.ops.quantize_x(x, self.index, *self.shard_widths)
+
+    def matmul_allreduce(self, qx, out: torch.Tensor | None = None, m: int | None = None) -> torch.Tensor:
+        import torch.distributed as dist
+        if self.empty:       # more ranks than 128-column granules: contribute zeros
+            if out is None:
+                raise ValueError("an empty shard needs `out` (or use forward)")
+            out.zero_()
+        else:
+            out = self.ops.matmul(qx, self.packed_w, out=out)
+        if self.world > 1:
+            dist.all_reduce(out, op=dist.ReduceOp.SUM, group=self.group)
+        if self.bias is not None:
+            out += self.bias
+        return out
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        lead = x.shape[:-1]
+        x2 = x.reshape(-1, self.K).contiguous()
+        out = torch.empty((x2.shape[0], self.N), dtype=torch.bfloat16, device=x2.device)
+        y = self.matmul_allreduce(self.quantize_x(x2), out=out)
+        return y.reshape(*lead, self.N)
+
+    __call__ = forward

@@ -257,20 +257,21 @@ def quantize_segment(v: np.ndarray, fmt: str):
 
 
 def reorder_quantize(x_bits: np.ndarray, idx: np.ndarray, kn: int, ks: int, ko: int,
-                     mode: str, sf_fill: int = 0):
+                     mode: str, sf_fill: int = 0, gather_subset: bool = False):
     """Restates run_reorder_quantize_{x,w,w4}.
 
     mode: "x"  activations, formats (fp4, fp6, fp8), SF sized sf_size_x
           "w"  weights,     formats (fp4, fp6, fp8), SF sized sf_size_w
           "w4" weights,     formats (fp4, fp4, fp4), SF sized sf_size_w
+    gather_subset: idx selects KN+KS+KO <= K columns (a tensor-parallel K-shard; not in the reference).
     Returns (ON, OS, OO, SFN, SFS, SFO); SF padding bytes are ``sf_fill``.
     """
     x_bits = np.asarray(x_bits)
     rows, k = x_bits.shape
-    check_split(k, kn, ks, ko)
+    check_split(kn + ks + ko if gather_subset else k, kn, ks, ko)
     idx = np.asarray(idx).astype(np.int64)
-    if idx.shape != (k,):
-        raise ValueError("reorder_index must have K entries")
+    if idx.shape != (kn + ks + ko,) or (len(idx) and (idx.min() < 0 or idx.max() >= k)):
+        raise ValueError("reorder_index must have KN+KS+KO entries in [0, K)")
     fmts = ("fp4", "fp4", "fp4") if mode == "w4" else ("fp4", "fp6", "fp8")
     v = bf16_to_f32(x_bits)[:, idx]                      # gather (reorder.cu:155-158)
     outs, sfs = [], []

@@ -1,0 +1,96 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads without a GPU, exports every
+symbol include/micromix_hip.h declares, its host-side helpers agree with the oracle, argument
+validation happens before any device work, and the Python `mixedgemm` surface mirrors the
+reference's pybind signatures (mgemm/src/bindings.cpp:682-742).  No kernel is launched here."""
+import inspect
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from micromix_amd import _lib, mixedgemm
+from oracle import mx_oracle as o
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    text = open(os.path.join(ROOT, "include", "micromix_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mm_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    declared = header_functions()
+    assert declared and set(declared) == set(_lib.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.mm_version() >= 100
+
+
+def test_host_helpers_match_oracle():
+    lib = _lib.load()
+    for m, k in ((1, 128), (127, 4096), (128, 4096), (130, 1024), (4096, 4096)):
+        assert lib.mm_sf_bytes_x(m, k) == o.sf_size_x(m, k)
+        assert lib.mm_sf_bytes_w(m, k) == o.sf_size_w(m, k)
+    rng = np.random.default_rng(1)
+    for _ in range(500):
+        r, j = int(rng.integers(0, 20000)), int(rng.integers(0, 448))
+        assert lib.mm_sf_offset(r, j, 14336) == int(o.sf_offset(r, j, 14336))
+
+
+def test_status_codes_without_device_work():
+    lib = _lib.load()
+    z = None
+    # bad splits are rejected before any pointer is touched (reference: "Value error in run_reorder_quantize_x")
+    for K, kn, ks, ko in ((4096, 100, 0, 3996), (4096, 2048, 1024, 512), (0, 0, 0, 0), (256, -128, 128, 256)):
+        assert lib.mm_reorder_quantize(z, 4, K, z, kn, ks, ko, 0, z, z, z, z, z, z, z) == _lib.MM_ERR_BAD_SPLIT
+    assert lib.mm_reorder_quantize(z, 0, 256, z, 256, 0, 0, 0, z, z, z, z, z, z, z) == _lib.MM_OK        # empty input
+    assert lib.mm_reorder_quantize(z, 4, 256, z, 256, 0, 0, 0, z, z, z, z, z, z, z) == _lib.MM_ERR_BAD_ARG  # null src
+    assert lib.mm_reorder_quantize(z, 4, 256, z, 256, 0, 0, 7, z, z, z, z, z, z, z) == _lib.MM_ERR_BAD_ARG  # bad mode
+    assert lib.mm_matmul(*[z] * 12, 0, 128, 128, 0, 0, 1, 0, z, z, z) == _lib.MM_OK                     # M == 0
+    assert lib.mm_matmul(*[z] * 12, 4, 128, 100, 0, 0, 1, 0, z, z, z) == _lib.MM_ERR_BAD_SPLIT
+    assert lib.mm_matmul(*[z] * 12, 4, 128, 128, 0, 0, 1, 0, z, z, z) == _lib.MM_ERR_BAD_ARG            # null D
+    assert lib.mm_strerror(_lib.MM_ERR_BAD_SPLIT).decode().startswith("KN, KS, KO")
+    with pytest.raises(RuntimeError, match="Value error in run_reorder_quantize_x"):
+        _lib.check(_lib.MM_ERR_BAD_SPLIT, "reorder_quantize_x")
+
+
+def test_python_surface_matches_reference_signatures():
+    # py::arg names of bindings.cpp:686-735
+    assert list(inspect.signature(mixedgemm.matmul).parameters)[:12] == [
+        "AN", "BN", "AS", "BS", "AO", "BO", "SFAN", "SFBN", "SFAS", "SFBS", "SFAO", "SFBO"]
+    for fn, first in ((mixedgemm.reorder_quantize_x, "X"), (mixedgemm.reorder_quantize_w, "W"),
+                      (mixedgemm.reorder_quantize_w4, "W")):
+        assert list(inspect.signature(fn).parameters) == [first, "reorder_index", "KN", "KS", "KO"]
+    for name in ("rmsnorm_quantize_x", "activate_quantize_x", "downproj_quantize_w", "downproj_quantize_w4",
+                 "batch_decode_i4", "init_kv_f16", "append_kv_i4"):
+        with pytest.raises(NotImplementedError):
+            getattr(mixedgemm, name)()
+
+
+def test_no_cpu_fallback():
+    x = torch.zeros((4, 256), dtype=torch.bfloat16)
+    idx = torch.arange(256, dtype=torch.int16)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        mixedgemm.reorder_quantize_x(x, idx, 256, 0, 0)
+    with pytest.raises(TypeError):
+        mixedgemm.reorder_quantize_x(x.float(), idx, 256, 0, 0)
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libmicromix_hip.so")
+    with pytest.raises(_lib.MicroMixLibraryError, match="no CPU fallback"):
+        _lib.load()
+
+
+def test_dropin_module_importable_by_path():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("mixedgemm_dropin", os.path.join(ROOT, "micromix_amd", "dropin", "mixedgemm.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.matmul is mixedgemm.matmul and mod.reorder_quantize_w4 is mixedgemm.reorder_quantize_w4

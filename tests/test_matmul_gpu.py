@@ -1,0 +1,188 @@
+"""GPU parity tests of mixedgemm.matmul (through the C ABI) against the oracle, within the
+tolerance stated in tests/gemm_check.py; bit-exact where the hardware arithmetic is exact."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import bits_from_t, make_inputs, t_from_bits, u8
+from gemm_check import check_gemm
+from micromix_amd import mixedgemm
+from oracle import mx_oracle as o
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+import make_golden as mg  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def to_dev(dev, arrs):
+    import torch
+    return [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in arrs]
+
+
+def gpu_matmul(dev, qx, qw, **kw):
+    import torch
+    a, b = to_dev(dev, qx), to_dev(dev, qw)
+    d = mixedgemm.matmul(a[0], b[0], a[1], b[1], a[2], b[2], a[3], b[3], a[4], b[4], a[5], b[5], **kw)
+    torch.cuda.synchronize()
+    return bits_from_t(d)
+
+
+def quantized(rng, m, n, k, split, wmode):
+    xb = make_inputs(rng, m, k)
+    wb = make_inputs(rng, n, k, "weight")
+    idx = rng.permutation(k).astype(np.int16)
+    return o.reorder_quantize(xb, idx, *split, "x"), o.reorder_quantize(wb, idx, *split, wmode)
+
+
+SHAPES = [
+    (128, 128, 128, (128, 0, 0)), (128, 128, 128, (0, 128, 0)), (128, 128, 128, (0, 0, 128)),
+    (1, 128, 512, (256, 128, 128)), (7, 256, 384, (128, 128, 128)), (33, 384, 1024, (512, 128, 384)),
+    (130, 256, 4096, (2048, 1024, 1024)), (257, 512, 1024, (0, 0, 1024)), (64, 200, 512, (256, 0, 256)),
+    (300, 1024, 2048, (1024, 0, 1024)), (96, 640, 5120, (4096, 512, 512)),
+]
+
+
+@pytest.mark.parametrize("wmode", ("w4", "w"))
+@pytest.mark.parametrize("rounding", ("reference", "fused"))
+@pytest.mark.parametrize("m,n,k,split", SHAPES)
+def test_matmul_matches_oracle(dev, wmode, rounding, m, n, k, split):
+    rng = np.random.default_rng(m * 7 + n * 3 + k)
+    qx, qw = quantized(rng, m, n, k, split, wmode)
+    got = gpu_matmul(dev, qx, qw, rounding=rounding)
+    check_gemm(got, qx, qw, rounding, label=f"{m}x{n}x{k} {split} {wmode} {rounding}")
+
+
+@pytest.mark.parametrize("split", [(512, 0, 0), (0, 512, 0), (256, 256, 0)])
+def test_exact_when_hardware_sums_exactly(dev, split):
+    """fp4 x fp4 and fp6 x fp4 blocks are summed exactly by the MFMA: with a single segment the result equals the
+    oracle bit for bit (production w4 weights), and also with two segments in fused rounding."""
+    rng = np.random.default_rng(5)
+    qx, qw = quantized(rng, 160, 256, 512, split, "w4")
+    for rounding in ("reference", "fused"):
+        got = gpu_matmul(dev, qx, qw, rounding=rounding)
+        want = mg.mm(qx, qw, rounding=rounding)
+        ulp = o.bf16_ulp_distance(got, want)
+        # fp32 accumulation order differs from the oracle's fp64 sum only below one fp32 ulp
+        assert ulp.max() <= 1 and (ulp > 0).mean() < 2e-3
+
+
+def test_small_integer_data_is_bit_exact(dev):
+    """operands whose products and sums are exactly representable: every format pair must be exact."""
+    rng = np.random.default_rng(6)
+    m, n, k = 96, 160, 384
+    xv = rng.integers(-3, 4, (m, k)).astype(np.float32)
+    wv = rng.integers(-2, 3, (n, k)).astype(np.float32) * 0.5
+    xv[:, ::32] = 6.0   # pins every block scale: amax = 6 -> e = 0 (fp4), -3 (fp6: 28*2^-3 < 6 <= 28*2^-2) ...
+    wv[:, ::32] = 3.0
+    idx = rng.permutation(k).astype(np.int16)
+    xb, wb = o.f32_to_bf16(xv), o.f32_to_bf16(wv)
+    for wmode in ("w4", "w"):
+        qx = o.reorder_quantize(xb, idx, 128, 128, 128, "x")
+        qw = o.reorder_quantize(wb, idx, 128, 128, 128, wmode)
+        got = gpu_matmul(dev, qx, qw, rounding="fused")
+        assert np.array_equal(got, mg.mm(qx, qw, rounding="fused"))
+        exact = o.f32_to_bf16((xv[:, idx.astype(int)] @ wv[:, idx.astype(int)].T).astype(np.float32))
+        assert np.array_equal(got, exact)   # small integers survive quantisation: equals the plain product
+
+
+def test_golden_gemm(dev):
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_v1.npz"))
+    xb, idx, wb = mg.g1_inputs(g["g1_special_rows"])
+    nsp = len(g["g1_special_rows"])
+    for si, split in enumerate(g["splits"].tolist()):
+        qx = o.reorder_quantize(xb, idx, *split, "x")
+        for mode in ("w", "w4"):
+            qw = o.reorder_quantize(wb, idx, *split, mode)
+            for rounding, key in (("reference", "ref"), ("fused", "fused")):
+                got = gpu_matmul(dev, qx, qw, rounding=rounding)
+                want = g[f"g3_{si}_{mode}_{key}"]
+                check_gemm(got[nsp:], _rows(qx, nsp), qw, rounding,
+                           label=f"golden {split} {mode} {rounding}")
+                ulp = o.bf16_ulp_distance(got[nsp:], want[nsp:])
+                assert (ulp > 1).mean() < 5e-3
+    for k in (14336, 5120):
+        x4, w4, i4 = mg.g4_inputs(k)
+        split = g[f"g4_{k}_split"].tolist()
+        qx, qw = o.reorder_quantize(x4, i4, *split, "x"), o.reorder_quantize(w4, i4, *split, "w4")
+        got = gpu_matmul(dev, qx, qw)
+        check_gemm(got, qx, qw, "reference", label=f"golden K={k}")
+        assert (o.bf16_ulp_distance(got, g[f"g4_{k}_d"]) > 1).mean() < 5e-3
+    x6, w6, i6 = mg.g6_inputs()
+    qx, qw = o.reorder_quantize(x6, i6, 0, 0, 1024, "x"), o.reorder_quantize(w6, i6, 0, 0, 1024, "w4")
+    got = gpu_matmul(dev, qx, qw)
+    check_gemm(got, qx, qw, "reference", label="golden test.py distribution")
+    assert (o.bf16_ulp_distance(got, g["g6_d"]) > 1).mean() < 5e-3
+
+
+def _rows(q, start):
+    """drop the first `start` rows of a quantised activation (SF tensors re-laid out)."""
+    m = q[0].shape[0]
+    out = [q[0][start:], q[1][start:], q[2][start:]]
+    widths = (q[0].shape[1] * 2, q[1].shape[1] * 4 // 3, q[2].shape[1])
+    for sf, kseg in zip(q[3:], widths):
+        new = np.zeros(o.sf_size_x(m - start, kseg), np.uint8)
+        if kseg:
+            r = np.arange(start, m)[:, None]
+            j = np.arange(kseg // 32)[None, :]
+            new[o.sf_offset(r - start, j, kseg)] = sf[o.sf_offset(r, j, kseg)]
+        out.append(new)
+    return out
+
+
+def test_bias_epilogue_equals_separate_add(dev):
+    import torch
+    rng = np.random.default_rng(8)
+    qx, qw = quantized(rng, 70, 384, 512, (256, 128, 128), "w4")
+    bias = o.f32_to_bf16(rng.standard_normal(384).astype(np.float32))
+    a, b = to_dev(dev, qx), to_dev(dev, qw)
+    args = (a[0], b[0], a[1], b[1], a[2], b[2], a[3], b[3], a[4], b[4], a[5], b[5])
+    tb = t_from_bits(bias, dev)
+    fused = mixedgemm.matmul(*args, bias=tb)
+    plain = mixedgemm.matmul(*args) + tb          # qLinearLayer.py:68-71
+    assert torch.equal(fused, plain)
+
+
+def test_full_size_properties(dev):
+    """BASELINE configs[1] size (4096^3, all-MXFP8 activations, both weight modes):
+    oracle on a row sample, exact power-of-two linearity, determinism, tile-independence."""
+    import torch
+    rng = np.random.default_rng(0)
+    M = N = K = 4096
+    xb = make_inputs(rng, M, K)
+    wb = make_inputs(rng, N, K, "weight")
+    idx = rng.permutation(K).astype(np.int16)
+    x, w, tidx = t_from_bits(xb, dev), t_from_bits(wb, dev), torch.from_numpy(idx).to(dev)
+    for split in ((0, 0, 4096), (2048, 128, 1920)):
+        a = mixedgemm.reorder_quantize_x(x, tidx, *split)
+        for fn in (mixedgemm.reorder_quantize_w4, mixedgemm.reorder_quantize_w):
+            b = fn(w, tidx, *split)
+            args = lambda aa: (aa[0], b[0], aa[1], b[1], aa[2], b[2], aa[3], b[3], aa[4], b[4], aa[5], b[5])
+            d1 = mixedgemm.matmul(*args(a))
+            d2 = mixedgemm.matmul(*args(a))
+            assert torch.equal(d1, d2)                                       # deterministic
+            # linearity: +1 on every activation scale byte doubles the output exactly
+            a2 = list(a[:3]) + [t + 1 for t in a[3:]]
+            assert torch.equal(mixedgemm.matmul(*args(a2)).float(), d1.float() * 2)
+            # a row block computed alone equals the same rows of the full product (tile independence)
+            r0, r1 = 1000, 1100
+            sub = mixedgemm.reorder_quantize_x(x[r0:r1].contiguous(), tidx, *split)
+            assert torch.equal(mixedgemm.matmul(*args(sub)), d1[r0:r1])
+            # oracle on a sample of rows
+            rows = np.sort(rng.choice(M, 48, replace=False))
+            qx = o.reorder_quantize(xb[rows], idx, *split, "x")
+            qw = [u8(t) for t in b]
+            check_gemm(bits_from_t(d1)[rows], qx, qw, "reference", label=f"4096^3 {split}")
+
+
+def test_errors(dev):
+    import torch
+    z = lambda *s: torch.zeros(s, dtype=torch.uint8, device=dev)
+    with pytest.raises(RuntimeError, match="BS has shape"):
+        mixedgemm.matmul(z(4, 64), z(8, 64), z(4, 96), z(8, 50), z(4, 0), z(8, 0), z(512), z(512), z(512), z(512), z(0), z(0))
+    with pytest.raises(RuntimeError, match="scale bytes"):
+        mixedgemm.matmul(z(4, 64), z(8, 64), z(4, 0), z(8, 0), z(4, 0), z(8, 0), z(4), z(512), z(0), z(0), z(0), z(0))
+    d = mixedgemm.matmul(z(4, 0), z(8, 0), z(4, 0), z(8, 0), z(4, 0), z(8, 0), z(0), z(0), z(0), z(0), z(0), z(0))
+    assert d.shape == (4, 8) and float(d.abs().sum()) == 0.0                 # K == 0 -> zeros (bindings.cpp:72)

@@ -1,0 +1,35 @@
+"""GPU test of the operator boundary: QLinearLayer (mirror of model/qLinearLayer.py) against the oracle."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import bits_from_t, t_from_bits
+from micromix_amd.qlinear import QLinearLayer, find_qlinear_layers
+from oracle import mx_oracle as o
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+import make_golden as mg  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def test_qlinear_forward_golden(dev):
+    import torch
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_v1.npz"))
+    x5, w5, b5, i5 = mg.g5_inputs()
+    p4, p6, p8 = g["g5_split"].tolist()
+    for with_bias, key in ((True, "g5_y"), (False, "g5_y_nobias")):
+        lin = torch.nn.Linear(1024, 256, bias=with_bias, dtype=torch.bfloat16)
+        lin.weight.data = t_from_bits(w5, "cpu")
+        if with_bias:
+            lin.bias.data = t_from_bits(b5, "cpu")
+        q = QLinearLayer(lin.to(dev), p8_num=p8, p6_num=p6, reorder_index=torch.from_numpy(i5.astype(np.int64)))
+        assert (q.p4_num, q.p6_num, q.p8_num) == (p4, p6, p8) and q.BS.shape == (256, p6 // 2)
+        y = q(t_from_bits(x5, dev).reshape(2, 20, 1024))
+        assert y.shape == (2, 20, 256) and y.dtype == torch.bfloat16
+        got = bits_from_t(y.reshape(40, 256))
+        ulp = o.bf16_ulp_distance(got, g[key])
+        assert (ulp > 1).mean() < 5e-3 and np.abs(o.bf16_to_f32(got) - o.bf16_to_f32(g[key])).max() < 0.25
+        assert list(find_qlinear_layers(torch.nn.Sequential(q))) == ["0"]

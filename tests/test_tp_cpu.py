@@ -1,0 +1,113 @@
+"""CPU tests of the tensor-parallel path: the K-shard planner, and a world_size-2 `gloo` run of
+TPShardedLinear whose per-rank compute is the oracle (the HIP kernels need a GPU; the partition, the
+sub-index gather, the SF bookkeeping and the all-reduce are what is under test here)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from micromix_amd import tp
+from oracle import mx_oracle as o
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+import lcg  # noqa: E402
+
+
+@pytest.mark.parametrize("split", [(0, 0, 4096), (2048, 128, 1920), (4096, 0, 0), (12288, 1024, 1024), (128, 0, 0),
+                                   (3584, 256, 256), (7168, 512, 6656)])
+@pytest.mark.parametrize("world", [1, 2, 4, 8])
+def test_plan_covers_every_column_once_and_balances_cost(split, world):
+    plan = tp.plan_k_shards(*split, world)
+    assert len(plan) == world
+    for s in range(3):
+        pos = 0
+        for r in range(world):
+            start, width = plan[r][s]
+            assert start == pos and width % 128 == 0 and width >= 0
+            pos += width
+        assert pos == split[s]
+    cost = [sum(plan[r][s][1] * tp.SEGMENT_COST[s] for s in range(3)) for r in range(world)]
+    assert max(cost) - min(cost) <= 128 * max(tp.SEGMENT_COST) + 1e-9     # within one granule of the heaviest kind
+
+
+def test_plan_rejects_bad_widths():
+    with pytest.raises(ValueError):
+        tp.plan_k_shards(100, 0, 28, 2)
+    with pytest.raises(ValueError):
+        tp.plan_k_shards(128, 0, 0, 0)
+
+
+class OracleOps:
+    """test-only compute backend: the CPU oracle behind the same three calls as the HIP backend."""
+
+    @staticmethod
+    def _bits(t):
+        return t.contiguous().view(torch.int16).numpy().view(np.uint16)
+
+    @classmethod
+    def quantize_w4(cls, w, index, kn, ks, ko):
+        return o.reorder_quantize(cls._bits(w), index.numpy(), kn, ks, ko, "w4", gather_subset=True)
+
+    @classmethod
+    def quantize_x(cls, x, index, kn, ks, ko):
+        return o.reorder_quantize(cls._bits(x), index.numpy(), kn, ks, ko, "x", gather_subset=True)
+
+    @staticmethod
+    def matmul(a, b, out=None):
+        d = o.matmul(a[0], b[0], a[1], b[1], a[2], b[2], a[3], b[3], a[4], b[4], a[5], b[5])
+        t = torch.from_numpy(d.view(np.int16).copy()).view(torch.bfloat16)
+        if out is not None:
+            out.copy_(t)
+            return out
+        return t
+
+
+def _inputs():
+    m, n, k, split = 24, 64, 1024, (512, 128, 384)
+    tb = lambda bits: torch.from_numpy(bits.view(np.int16).copy()).view(torch.bfloat16)
+    x = tb(lcg.bf16_normalish(1, (m, k)))
+    w = tb(lcg.bf16_normalish(2, (n, k), exp_center=122))
+    idx = torch.from_numpy(lcg.permutation(3, k))
+    return m, n, k, split, x, w, idx
+
+
+def _worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        m, n, k, split, x, w, idx = _inputs()
+        layer = tp.TPShardedLinear(w, idx, *split, rank=rank, world=world, group=dist.group.WORLD, ops=OracleOps)
+        y = layer(x.reshape(2, m // 2, k))
+        assert y.shape == (2, m // 2, n)
+        ret[rank] = (layer.shard_widths, y.reshape(m, n).float().numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_matches_unsharded_oracle():
+    world = 2
+    port = 29500 + os.getpid() % 2000
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+        res = dict(ret)
+    m, n, k, split, x, w, idx = _inputs()
+    bits = OracleOps._bits
+    qx = o.reorder_quantize(bits(x), idx.numpy(), *split, "x")
+    qw = o.reorder_quantize(bits(w), idx.numpy(), *split, "w4")
+    want, f64 = o.matmul(qx[0], qw[0], qx[1], qw[1], qx[2], qw[2], qx[3], qw[3], qx[4], qw[4], qx[5], qw[5],
+                         rounding="fused", return_f64=True)
+    assert np.array_equal(res[0][1], res[1][1])                       # all-reduce: every rank holds the sum
+    assert [sum(wd) for wd in zip(res[0][0], res[1][0])] == list(split)
+    got = res[0][1].astype(np.float64)
+    # each rank rounds its partial (3 segment roundings) to bf16, the all-reduce adds them in bf16: a few ulps of the
+    # partial magnitudes.  |partials| <= S, the absolute dot product.
+    a = [o.dequant_segment(qx[i], qx[3 + i], m, split[i], f) for i, f in enumerate(("fp4", "fp6", "fp8"))]
+    b = [o.dequant_segment(qw[i], qw[3 + i], n, split[i], "fp4") for i in range(3)]
+    S = sum(np.abs(ai).astype(np.float64) @ np.abs(bi).astype(np.float64).T for ai, bi in zip(a, b))
+    assert np.all(np.abs(got - f64) <= 2.0 ** -7 * (np.abs(f64) + 0.25 * S) + 1e-30)
+    assert np.linalg.norm(got - f64) / np.linalg.norm(f64) < 4e-3
