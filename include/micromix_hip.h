@@ -126,6 +126,17 @@ int mm_diag_hw_convert(const void *src_bf16, int n, float scale, int el, uint8_t
 int mm_diag_mfma_rate(int shape, int el_a, int el_b, int blocks, int iters, const void *seed_regs, void *sink,
                       mm_stream_t stream);
 
+/* Diagnostics: when a device buffer of 4 x 8 bytes per workgroup is registered, the large-M GEMM kernel stores
+ * {main-loop s_memtime delta, main-loop s_memrealtime delta, start tick, end-of-epilogue tick delta} of every workgroup
+ * there (in-kernel clock = ratio x 100 MHz); NULL disables. */
+int mm_diag_set_clock_buffer(void *buf);
+
+/* L2 -> CU read-bandwidth microbenchmark (kernel-developer tool): `blocks` workgroups each move kb_per_iter KiB per
+ * iteration from a hot region; mode 0 = register loads, 1 = contiguous LDS-DMA, 2 = LDS-DMA of 8 x 128-byte rows
+ * `stride` bytes apart. */
+int mm_diag_l2_bw(const void *buf, unsigned region, int stride, int kb_per_iter, int iters, int mode, int blocks, void *sink,
+                  mm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

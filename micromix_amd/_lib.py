@@ -9,14 +9,15 @@ import ctypes
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "lib", "libmicromix_hip.so")
+# MICROMIX_HIP_LIB lets a kernel developer A/B an experimental build of the same C ABI (never a fallback).
+LIB_PATH = os.environ.get("MICROMIX_HIP_LIB") or os.path.join(_PKG, "lib", "libmicromix_hip.so")
 
 # every symbol include/micromix_hip.h declares
 EXPORTS = (
     "mm_version", "mm_strerror", "mm_last_error",
     "mm_sf_bytes_x", "mm_sf_bytes_w", "mm_sf_offset",
     "mm_reorder_quantize", "mm_reorder_quantize_gather", "mm_matmul",
-    "mm_diag_mfma", "mm_diag_hw_convert", "mm_diag_mfma_rate",
+    "mm_diag_mfma", "mm_diag_hw_convert", "mm_diag_mfma_rate", "mm_diag_l2_bw", "mm_diag_set_clock_buffer",
 )
 
 MM_OK, MM_ERR_BAD_SPLIT, MM_ERR_BAD_ARG, MM_ERR_LAUNCH, MM_ERR_UNSUPPORTED, MM_ERR_NO_DEVICE = range(6)
@@ -66,6 +67,10 @@ def load():
     lib.mm_diag_hw_convert.argtypes = [vp, i, ctypes.c_float, i, vp, vp]
     lib.mm_diag_mfma_rate.restype = i
     lib.mm_diag_mfma_rate.argtypes = [i, i, i, i, i, vp, vp, vp]
+    lib.mm_diag_l2_bw.restype = i
+    lib.mm_diag_l2_bw.argtypes = [vp, ctypes.c_uint, i, i, i, i, i, vp, vp]
+    lib.mm_diag_set_clock_buffer.restype = i
+    lib.mm_diag_set_clock_buffer.argtypes = [vp]
     _lib = lib
     return lib
 

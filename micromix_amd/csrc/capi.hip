@@ -8,6 +8,7 @@
 
 
 static thread_local char g_last_error[256] = "";
+static unsigned long long *g_clock_buf = nullptr;  // diagnostics: see mm_diag_set_clock_buffer
 
 static int fail_hip(hipError_t e, const char *where) {
     snprintf(g_last_error, sizeof(g_last_error), "%s: %s", where, hipGetErrorString(e));
@@ -95,8 +96,14 @@ int mm_matmul(const uint8_t *AN, const uint8_t *BN, const uint8_t *AS, const uin
     a.round_per_segment = (flags & MM_ROUND_ONCE) ? 0 : 1;
     a.bias = (const uint16_t *)bias_bf16;
     a.D = (uint16_t *)D_bf16;
+    a.clock_out = g_clock_buf;
     hipError_t e = mm::launch_mx_gemm(a, wmode == MM_W_FP4, (hipStream_t)stream);
     return e == hipSuccess ? MM_OK : fail_hip(e, "mm_matmul");
+}
+
+int mm_diag_set_clock_buffer(void *buf) {
+    g_clock_buf = (unsigned long long *)buf;
+    return MM_OK;
 }
 
 }  // extern "C"

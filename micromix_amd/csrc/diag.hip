@@ -207,3 +207,68 @@ int mm_diag_hw_convert(const void *src_bf16, int n, float scale, int el, uint8_t
     return hipGetLastError() == hipSuccess ? MM_OK : MM_ERR_LAUNCH;
 }
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// L2 -> CU read-bandwidth microbenchmark (kernel-developer tool, not on the product path).
+//   mode 0: global_load_dwordx4 to registers, 1 KiB contiguous per wave instruction
+//   mode 1: LDS-DMA, 1 KiB contiguous per wave instruction
+//   mode 2: LDS-DMA, 8 rows x 128 B per wave instruction, rows `stride` bytes apart (the GEMM's operand pattern)
+// Every workgroup (256 threads) moves `kb_per_iter` KiB per iteration from a hot region of `region` bytes.
+// ---------------------------------------------------------------------------------------------------------
+namespace mm {
+typedef int rsrc4_t __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256) diag_l2_bw(const uint8_t *buf, unsigned region, int stride, int kb_per_iter, int iters,
+                                                  int mode, float *sink) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const unsigned long long v = (unsigned long long)buf;
+    rsrc4_t rsrc;
+    rsrc[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)v);
+    rsrc[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(v >> 32) & 0xFFFFu));
+    rsrc[2] = __builtin_amdgcn_readfirstlane((int)region);
+    rsrc[3] = 0x00020000;
+    const unsigned mask = region - 1;  // region is a power of two
+    const unsigned base = (blockIdx.x * 65536u) & mask;
+    float acc = 0.0f;
+    for (int it = 0; it < iters; ++it) {
+        for (int p = 0; p < kb_per_iter / 4; ++p) {  // each wave moves 1 KiB per instruction, 4 waves
+            unsigned off;
+            if (mode == 2) {
+                const int row = (p * 32 + wave * 8 + (lane >> 3));
+                off = (base + (unsigned)row * (unsigned)stride + (unsigned)(it & 31) * 128u + (lane & 7) * 16u) & mask;
+            } else {
+                off = (base + (unsigned)(it & 31) * 49152u + (unsigned)(p * 4 + wave) * 1024u + lane * 16u) & mask;
+            }
+            if (mode == 0) {
+                const uint4 q = *reinterpret_cast<const uint4 *>(buf + off);
+                acc += __uint_as_float(q.x ^ q.y ^ q.z ^ q.w);
+            } else {
+                const unsigned lds = __builtin_amdgcn_readfirstlane((unsigned)(((p & 31) * 4 + wave) * 1024));
+                unsigned keep;
+                asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                             "buffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep)
+                             : "v"((int)off), "s"(rsrc), "s"(lds)
+                             : "memory");
+            }
+        }
+        if (mode != 0) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (acc == 12345.678f) sink[0] = acc + smem[tid];
+}
+}  // namespace mm
+
+extern "C" int mm_diag_l2_bw(const void *buf, unsigned region, int stride, int kb_per_iter, int iters, int mode, int blocks,
+                             void *sink, mm_stream_t stream) {
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(mm::diag_l2_bw), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                131072) != hipSuccess)
+            return MM_ERR_LAUNCH;
+        attr = true;
+    }
+    hipLaunchKernelGGL(mm::diag_l2_bw, dim3(blocks), dim3(256), 131072, (hipStream_t)stream, (const uint8_t *)buf, region, stride,
+                       kb_per_iter, iters, mode, (float *)sink);
+    return hipGetLastError() == hipSuccess ? MM_OK : MM_ERR_LAUNCH;
+}

@@ -17,11 +17,13 @@ struct GemmArgs {
     int round_per_segment;
     const uint16_t *bias;   // optional [N] bf16
     uint16_t *D;            // [M, N] bf16
+    unsigned long long *clock_out;  // diagnostics only (mm_diag_set_clock_buffer): per workgroup {shader cycles, 100 MHz ticks}
 };
 
 hipError_t launch_reorder_quantize(const void *src, int rows, int K, const int16_t *idx, int KN, int KS, int KO, bool w4,
                                    uint8_t *oN, uint8_t *oS, uint8_t *oO, uint8_t *sfN, uint8_t *sfS, uint8_t *sfO,
                                    hipStream_t stream);
 hipError_t launch_mx_gemm(const GemmArgs &a, bool w4, hipStream_t stream);
+hipError_t launch_mx_gemm256(const GemmArgs &a, bool w4, hipStream_t stream);
 
 }  // namespace mm
