@@ -13,37 +13,97 @@
 //    (the reference re-reads each index from global memory per element);
 //  * the row is staged in LDS with 16-byte coalesced loads; the next row's loads are
 //    issued before the current row's gather so HBM latency hides under the LDS work;
-//  * all scale arithmetic is integer/exponent arithmetic (no log2/ceil/ldexp/divide).
+//  * all scale arithmetic is integer/exponent arithmetic (no log2/ceil/ldexp/divide); the element conversion is
+//    one hardware MX-converter instruction per 2 (fp4/fp8) or 32 (fp6) elements.
 #include "mx_common.h"
 #include "mx_kernels.h"
 
 namespace mm {
 
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf32 __attribute__((ext_vector_type(32)));
+typedef short s2 __attribute__((ext_vector_type(2)));
+typedef unsigned u6 __attribute__((ext_vector_type(6)));
+
+// One 32-element group: gather (two bf16 per VGPR), block absmax, UE8M0 scale, convert, pack, store.
+// Conversion uses the CDNA4 MX converters (v_cvt_scalef32_pk_fp4_bf16 / _pk_fp8_bf16 / _pk32_bf6_bf16: dst =
+// RNE(src / scale), saturating) -- tests/test_hw_gpu.py checks them code-for-code against the oracle's encoders for every
+// finite bf16, and tests/test_quantize_gpu.py checks the kernel's bytes.  A block whose scale exponent is -127 (only
+// possible when every element is below 6 * 2^-127) takes the integer encoder instead: 2^-127 is not a normal fp32.
 template <int EL>
 __device__ __forceinline__ void quantize_group(const uint16_t *__restrict__ row, const uint32_t (&ix)[16],
                                                uint8_t *__restrict__ out, uint8_t *__restrict__ sf) {
-    uint32_t v[32];
-    uint32_t amax = 0;
+    uint32_t v[16];  // v[i] = {element 2i (low half), element 2i+1 (high half)}
+    us2 amax2 = {0, 0};
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-        const uint32_t a = row[ix[i] & 0xFFFFu];
-        const uint32_t b = row[ix[i] >> 16];
-        v[2 * i] = a;
-        v[2 * i + 1] = b;
-        const uint32_t ma = a & 0x7FFFu, mb = b & 0x7FFFu;
-        amax = amax > ma ? amax : ma;
-        amax = amax > mb ? amax : mb;
+        const uint32_t lo = row[ix[i] & 0xFFFFu];
+        const uint32_t hi = row[ix[i] >> 16];
+        v[i] = lo | (hi << 16);
+        const uint32_t mag = v[i] & 0x7FFF7FFFu;
+        us2 m;
+        __builtin_memcpy(&m, &mag, 4);
+        amax2 = __builtin_elementwise_max(amax2, m);
     }
+    const uint32_t amax = amax2[0] > amax2[1] ? amax2[0] : amax2[1];
     const int e = scale_exponent<EL>(amax << 16);
     *sf = (uint8_t)(e + 127);
-    // 2^-e as fp32.  e <= 126 for any finite bf16 amax (bf16 max / 6 < 2^126), so 127 - e >= 1 is a
-    // normal exponent field; e >= -127 gives at most 254.
-    const float rs = __uint_as_float((uint32_t)(127 - e) << 23);
 
+    if (e > -127) {
+        const float scale = __uint_as_float((uint32_t)(127 + e) << 23);  // 2^e, a normal fp32
+        if constexpr (EL == EL_FP8) {
+            uint32_t w[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                bf2 a, b;
+                __builtin_memcpy(&a, &v[2 * i], 4);
+                __builtin_memcpy(&b, &v[2 * i + 1], 4);
+                s2 r = {0, 0};
+                r = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(r, a, scale, false);
+                r = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(r, b, scale, true);
+                __builtin_memcpy(&w[i], &r, 4);
+            }
+            uint4 *o = reinterpret_cast<uint4 *>(out);
+            o[0] = make_uint4(w[0], w[1], w[2], w[3]);
+            o[1] = make_uint4(w[4], w[5], w[6], w[7]);
+        } else if constexpr (EL == EL_FP4) {
+            uint32_t w[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                uint32_t r = 0;
+                bf2 a;
+                __builtin_memcpy(&a, &v[4 * i], 4);
+                r = __builtin_amdgcn_cvt_scalef32_pk_fp4_bf16(r, a, scale, 0);
+                __builtin_memcpy(&a, &v[4 * i + 1], 4);
+                r = __builtin_amdgcn_cvt_scalef32_pk_fp4_bf16(r, a, scale, 1);
+                __builtin_memcpy(&a, &v[4 * i + 2], 4);
+                r = __builtin_amdgcn_cvt_scalef32_pk_fp4_bf16(r, a, scale, 2);
+                __builtin_memcpy(&a, &v[4 * i + 3], 4);
+                r = __builtin_amdgcn_cvt_scalef32_pk_fp4_bf16(r, a, scale, 3);
+                w[i] = r;
+            }
+            *reinterpret_cast<uint4 *>(out) = make_uint4(w[0], w[1], w[2], w[3]);
+        } else {
+            bf32 x;
+            __builtin_memcpy(&x, v, 64);
+            const u6 r = __builtin_amdgcn_cvt_scalef32_pk32_bf6_bf16(x, scale);
+            uint2 *o = reinterpret_cast<uint2 *>(out);
+            o[0] = make_uint2(r[0], r[1]);
+            o[1] = make_uint2(r[2], r[3]);
+            o[2] = make_uint2(r[4], r[5]);
+        }
+        return;
+    }
+
+    // rare: e == -127
+    const float rs = __uint_as_float(254u << 23);  // 2^127
     uint32_t c[32];
 #pragma unroll
-    for (int i = 0; i < 32; ++i) c[i] = encode<EL>(bf16_bits_to_f32(v[i]) * rs);
-
+    for (int i = 0; i < 16; ++i) {
+        c[2 * i] = encode<EL>(bf16_bits_to_f32(v[i] & 0xFFFFu) * rs);
+        c[2 * i + 1] = encode<EL>(bf16_bits_to_f32(v[i] >> 16) * rs);
+    }
     if constexpr (EL == EL_FP8) {
         uint32_t w[8];
 #pragma unroll

@@ -33,6 +33,7 @@ def _stream_ptr(device) -> int:
 
 
 def _check_tensor(t, name, dtype, device=None):
+    """Slow path: produces the precise error.  The ops call it only after the cheap combined test failed."""
     if not isinstance(t, torch.Tensor):
         raise TypeError(f"{name} must be a torch.Tensor")
     if t.dtype != dtype:
@@ -45,14 +46,49 @@ def _check_tensor(t, name, dtype, device=None):
         raise RuntimeError(f"{name} must be contiguous")
 
 
+def _ok(t, dtype, index) -> bool:
+    # one short-circuit expression per tensor: ~0.3 us instead of ~0.7 us for the descriptive checks
+    return t.dtype is dtype and t.is_cuda and t.get_device() == index and t.is_contiguous()
+
+
 def _ptr(t):
     return t.data_ptr() if t.numel() else None
 
 
+def _sf_bytes_x(m, k):   # bindings.cpp:120-123
+    return (m // 128 + 1) * 128 * (k // 32)
+
+
+def _sf_bytes_w(n, k):   # bindings.cpp:170-172 (rows padded to 128)
+    return (n + 127) // 128 * 128 * (k // 32)
+
+
+class _on_device:
+    """`with torch.cuda.device(d)` only when d is not already current (saves ~2 us per call)."""
+    __slots__ = ("idx", "prev")
+
+    def __init__(self, idx):
+        self.idx = idx
+        self.prev = -1
+
+    def __enter__(self):
+        cur = torch.cuda.current_device()
+        if cur != self.idx:
+            self.prev = cur
+            torch.cuda.set_device(self.idx)
+
+    def __exit__(self, *exc):
+        if self.prev >= 0:
+            torch.cuda.set_device(self.prev)
+        return False
+
+
 def _quantize(src, reorder_index, KN, KS, KO, mode, what, gather_subset=False):
     lib = _lib.load()
-    _check_tensor(src, "X" if mode == "x" else "W", torch.bfloat16)
-    _check_tensor(reorder_index, "reorder_index", torch.int16, src.device)
+    if not (isinstance(src, torch.Tensor) and isinstance(reorder_index, torch.Tensor) and src.is_cuda
+            and _ok(src, torch.bfloat16, src.get_device()) and _ok(reorder_index, torch.int16, src.get_device())):
+        _check_tensor(src, "X" if mode == "x" else "W", torch.bfloat16)
+        _check_tensor(reorder_index, "reorder_index", torch.int16, src.device)
     if src.dim() != 2:
         raise RuntimeError("input must be 2-D [rows, K]")
     KN, KS, KO = int(KN), int(KS), int(KO)
@@ -63,22 +99,24 @@ def _quantize(src, reorder_index, KN, KS, KO, mode, what, gather_subset=False):
         _lib.check(_lib.MM_ERR_BAD_SPLIT, what)
     if (KN + KS + KO != K) if not gather_subset else (KN + KS + KO > K or KN + KS + KO == 0):
         _lib.check(_lib.MM_ERR_BAD_SPLIT, what)
-    opt = dict(dtype=torch.uint8, device=src.device)
+    dev = src.device
     w4 = mode == "w4"
-    oN = torch.empty((rows, KN // 2), **opt)
-    oS = torch.empty((rows, KS // 2 if w4 else KS // 4 * 3), **opt)
-    oO = torch.empty((rows, KO // 2 if w4 else KO), **opt)
-    sf_bytes = lib.mm_sf_bytes_x if mode == "x" else lib.mm_sf_bytes_w
-    sfN = torch.empty((sf_bytes(rows, KN),), **opt)
-    sfS = torch.empty((sf_bytes(rows, KS),), **opt)
-    sfO = torch.empty((sf_bytes(rows, KO),), **opt)
-    with torch.cuda.device(src.device):
+    u8 = torch.uint8
+    oN = torch.empty((rows, KN // 2), dtype=u8, device=dev)
+    oS = torch.empty((rows, KS // 2 if w4 else KS // 4 * 3), dtype=u8, device=dev)
+    oO = torch.empty((rows, KO // 2 if w4 else KO), dtype=u8, device=dev)
+    sf_bytes = _sf_bytes_x if mode == "x" else _sf_bytes_w
+    sfN = torch.empty((sf_bytes(rows, KN),), dtype=u8, device=dev)
+    sfS = torch.empty((sf_bytes(rows, KS),), dtype=u8, device=dev)
+    sfO = torch.empty((sf_bytes(rows, KO),), dtype=u8, device=dev)
+    with _on_device(dev.index):
         entry = lib.mm_reorder_quantize_gather if gather_subset else lib.mm_reorder_quantize
         st = entry(
             _ptr(src), rows, K, _ptr(reorder_index), KN, KS, KO,
             _lib.MM_QUANT_W4 if w4 else _lib.MM_QUANT_MIXED,
-            _ptr(oN), _ptr(oS), _ptr(oO), _ptr(sfN), _ptr(sfS), _ptr(sfO), _stream_ptr(src.device))
-    _lib.check(st, what)
+            _ptr(oN), _ptr(oS), _ptr(oO), _ptr(sfN), _ptr(sfS), _ptr(sfO), _stream_ptr(dev))
+    if st:
+        _lib.check(st, what)
     return oN, oS, oO, sfN, sfS, sfO
 
 
@@ -104,44 +142,59 @@ def matmul(AN, BN, AS, BS, AO, BO, SFAN, SFBN, SFAS, SFBS, SFAO, SFBO, *, bias=N
     from `AS.size(1) == BS.size(1) and AO.size(1) == BO.size(1)` (bindings.cpp:74,87).
     """
     lib = _lib.load()
-    dev = AN.device
-    names = ("AN", "BN", "AS", "BS", "AO", "BO", "SFAN", "SFBN", "SFAS", "SFBS", "SFAO", "SFBO")
     tensors = (AN, BN, AS, BS, AO, BO, SFAN, SFBN, SFAS, SFBS, SFAO, SFBO)
-    for n, t in zip(names, tensors):
-        _check_tensor(t, n, torch.uint8, dev)
+    dev = AN.device
+    index = dev.index
+    u8 = torch.uint8
+    for t in tensors:
+        if not _ok(t, u8, index):
+            names = ("AN", "BN", "AS", "BS", "AO", "BO", "SFAN", "SFBN", "SFAS", "SFBS", "SFAO", "SFBO")
+            for n, tt in zip(names, tensors):
+                _check_tensor(tt, n, u8, dev)
     M, N = AN.size(0), BN.size(0)
-    KN, KS, KO = AN.size(1) * 2, AS.size(1) * 4 // 3, AO.size(1)
-    same = AS.size(1) == BS.size(1) and AO.size(1) == BO.size(1)
+    as1, ao1, bs1, bo1 = AS.size(1), AO.size(1), BS.size(1), BO.size(1)
+    KN, KS, KO = AN.size(1) * 2, as1 * 4 // 3, ao1
+    same = as1 == bs1 and ao1 == bo1
     wmode = _lib.MM_W_MATCH if same else _lib.MM_W_FP4
-    exp_b = (KN // 2, KS // 4 * 3 if same else KS // 2, KO if same else KO // 2)
-    for n, t, w in zip(("BN", "BS", "BO"), (BN, BS, BO), exp_b):
-        if t.dim() != 2 or t.size(0) != N or t.size(1) != w:
-            raise RuntimeError(f"{n} has shape {tuple(t.shape)}, expected ({N}, {w})")
-    for n, t in zip(("AS", "AO"), (AS, AO)):
-        if t.dim() != 2 or t.size(0) != M:
-            raise RuntimeError(f"{n} must be [M, bytes]")
-    for n, t, rows_bytes in (("SFAN", SFAN, lib.mm_sf_bytes_w(M, KN)), ("SFAS", SFAS, lib.mm_sf_bytes_w(M, KS)),
-                             ("SFAO", SFAO, lib.mm_sf_bytes_w(M, KO)), ("SFBN", SFBN, lib.mm_sf_bytes_w(N, KN)),
-                             ("SFBS", SFBS, lib.mm_sf_bytes_w(N, KS)), ("SFBO", SFBO, lib.mm_sf_bytes_w(N, KO))):
-        if t.numel() < rows_bytes:
-            raise RuntimeError(f"{n} holds {t.numel()} scale bytes, needs at least {rows_bytes}")
-    if rounding not in ("reference", "fused"):
+    if (BN.size(1) != KN // 2 or bs1 != (KS // 4 * 3 if same else KS // 2) or bo1 != (KO if same else KO // 2)
+            or BS.size(0) != N or BO.size(0) != N or BN.dim() != 2):
+        exp_b = (KN // 2, KS // 4 * 3 if same else KS // 2, KO if same else KO // 2)
+        for n, t, w in zip(("BN", "BS", "BO"), (BN, BS, BO), exp_b):
+            if t.dim() != 2 or t.size(0) != N or t.size(1) != w:
+                raise RuntimeError(f"{n} has shape {tuple(t.shape)}, expected ({N}, {w})")
+    if AS.size(0) != M or AO.size(0) != M:
+        raise RuntimeError("AS and AO must be [M, bytes]")
+    if (SFAN.numel() < _sf_bytes_w(M, KN) or SFAS.numel() < _sf_bytes_w(M, KS) or SFAO.numel() < _sf_bytes_w(M, KO)
+            or SFBN.numel() < _sf_bytes_w(N, KN) or SFBS.numel() < _sf_bytes_w(N, KS) or SFBO.numel() < _sf_bytes_w(N, KO)):
+        for n, t, need in (("SFAN", SFAN, _sf_bytes_w(M, KN)), ("SFAS", SFAS, _sf_bytes_w(M, KS)),
+                           ("SFAO", SFAO, _sf_bytes_w(M, KO)), ("SFBN", SFBN, _sf_bytes_w(N, KN)),
+                           ("SFBS", SFBS, _sf_bytes_w(N, KS)), ("SFBO", SFBO, _sf_bytes_w(N, KO))):
+            if t.numel() < need:
+                raise RuntimeError(f"{n} holds {t.numel()} scale bytes, needs at least {need}")
+    if rounding == "reference":
+        flags = _lib.MM_ROUND_PER_SEGMENT
+    elif rounding == "fused":
+        flags = _lib.MM_ROUND_ONCE
+    else:
         raise ValueError("rounding must be 'reference' or 'fused'")
-    flags = _lib.MM_ROUND_PER_SEGMENT if rounding == "reference" else _lib.MM_ROUND_ONCE
     if bias is not None:
-        _check_tensor(bias, "bias", torch.bfloat16, dev)
+        if not _ok(bias, torch.bfloat16, index):
+            _check_tensor(bias, "bias", torch.bfloat16, dev)
         if bias.numel() != N:
             raise RuntimeError("bias must have N elements")
     if out is None:
         out = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
     else:
-        _check_tensor(out, "out", torch.bfloat16, dev)
-        if tuple(out.shape) != (M, N):
+        if not _ok(out, torch.bfloat16, index):
+            _check_tensor(out, "out", torch.bfloat16, dev)
+        if out.dim() != 2 or out.size(0) != M or out.size(1) != N:
             raise RuntimeError("out has the wrong shape")
-    with torch.cuda.device(dev):
-        st = lib.mm_matmul(*[_ptr(t) for t in tensors], M, N, KN, KS, KO, wmode, flags,
+    with _on_device(index):
+        st = lib.mm_matmul(_ptr(AN), _ptr(BN), _ptr(AS), _ptr(BS), _ptr(AO), _ptr(BO), _ptr(SFAN), _ptr(SFBN),
+                           _ptr(SFAS), _ptr(SFBS), _ptr(SFAO), _ptr(SFBO), M, N, KN, KS, KO, wmode, flags,
                            _ptr(bias) if bias is not None else None, _ptr(out), _stream_ptr(dev))
-    _lib.check(st, "matmul")
+    if st:
+        _lib.check(st, "matmul")
     return out
 
 
