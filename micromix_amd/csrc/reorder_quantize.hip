@@ -16,6 +16,9 @@
 //  * all scale arithmetic is integer/exponent arithmetic (no log2/ceil/ldexp/divide); the element conversion is
 //    one hardware MX-converter instruction per 2 (fp4/fp8) or 32 (fp6) elements.
 #include "mx_common.h"
+#ifndef MM_QDBG
+#define MM_QDBG 0  // kernel-developer A/B switches: 1 = tiny-block path out of line, 2 = byte SF stores, 4 = fixed 2048-block grid
+#endif
 #include "mx_kernels.h"
 
 namespace mm {
@@ -26,77 +29,16 @@ typedef __bf16 bf32 __attribute__((ext_vector_type(32)));
 typedef short s2 __attribute__((ext_vector_type(2)));
 typedef unsigned u6 __attribute__((ext_vector_type(6)));
 
-// One 32-element group: gather (two bf16 per VGPR), block absmax, UE8M0 scale, convert, pack, store.
-// Conversion uses the CDNA4 MX converters (v_cvt_scalef32_pk_fp4_bf16 / _pk_fp8_bf16 / _pk32_bf6_bf16: dst =
-// RNE(src / scale), saturating) -- tests/test_hw_gpu.py checks them code-for-code against the oracle's encoders for every
-// finite bf16, and tests/test_quantize_gpu.py checks the kernel's bytes.  A block whose scale exponent is -127 (only
-// possible when every element is below 6 * 2^-127) takes the integer encoder instead: 2^-127 is not a normal fp32.
+// e == -127 (every element of the block is below FMAX * 2^-127): 2^127 times the value, integer encoder.
+// Inlined on purpose: as a __noinline__ call it cost 40 % of the kernel's time (15.3 vs 10.9 us at 4096 x 4096) although
+// it is practically never taken -- the call site pins the caller's registers.
+#if (MM_QDBG & 1)
+#define MM_TINY_INLINE __noinline__
+#else
+#define MM_TINY_INLINE __forceinline__
+#endif
 template <int EL>
-__device__ __forceinline__ void quantize_group(const uint16_t *__restrict__ row, const uint32_t (&ix)[16],
-                                               uint8_t *__restrict__ out, uint8_t *__restrict__ sf) {
-    uint32_t v[16];  // v[i] = {element 2i (low half), element 2i+1 (high half)}
-    us2 amax2 = {0, 0};
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const uint32_t lo = row[ix[i] & 0xFFFFu];
-        const uint32_t hi = row[ix[i] >> 16];
-        v[i] = lo | (hi << 16);
-        const uint32_t mag = v[i] & 0x7FFF7FFFu;
-        us2 m;
-        __builtin_memcpy(&m, &mag, 4);
-        amax2 = __builtin_elementwise_max(amax2, m);
-    }
-    const uint32_t amax = amax2[0] > amax2[1] ? amax2[0] : amax2[1];
-    const int e = scale_exponent<EL>(amax << 16);
-    *sf = (uint8_t)(e + 127);
-
-    if (e > -127) {
-        const float scale = __uint_as_float((uint32_t)(127 + e) << 23);  // 2^e, a normal fp32
-        if constexpr (EL == EL_FP8) {
-            uint32_t w[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                bf2 a, b;
-                __builtin_memcpy(&a, &v[2 * i], 4);
-                __builtin_memcpy(&b, &v[2 * i + 1], 4);
-                s2 r = {0, 0};
-                r = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(r, a, scale, false);
-                r = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(r, b, scale, true);
-                __builtin_memcpy(&w[i], &r, 4);
-            }
-            uint4 *o = reinterpret_cast<uint4 *>(out);
-            o[0] = make_uint4(w[0], w[1], w[2], w[3]);
-            o[1] = make_uint4(w[4], w[5], w[6], w[7]);
-        } else if constexpr (EL == EL_FP4) {
-            uint32_t w[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                uint32_t r = 0;
-                bf2 a;
-                __builtin_memcpy(&a, &v[4 * i], 4);
-                r = __builtin_amdgcn_cvt_scalef32_pk_fp4_bf16(r, a, scale, 0);
-                __builtin_memcpy(&a, &v[4 * i + 1], 4);
-                r = __builtin_amdgcn_cvt_scalef32_pk_fp4_bf16(r, a, scale, 1);
-                __builtin_memcpy(&a, &v[4 * i + 2], 4);
-                r = __builtin_amdgcn_cvt_scalef32_pk_fp4_bf16(r, a, scale, 2);
-                __builtin_memcpy(&a, &v[4 * i + 3], 4);
-                r = __builtin_amdgcn_cvt_scalef32_pk_fp4_bf16(r, a, scale, 3);
-                w[i] = r;
-            }
-            *reinterpret_cast<uint4 *>(out) = make_uint4(w[0], w[1], w[2], w[3]);
-        } else {
-            bf32 x;
-            __builtin_memcpy(&x, v, 64);
-            const u6 r = __builtin_amdgcn_cvt_scalef32_pk32_bf6_bf16(x, scale);
-            uint2 *o = reinterpret_cast<uint2 *>(out);
-            o[0] = make_uint2(r[0], r[1]);
-            o[1] = make_uint2(r[2], r[3]);
-            o[2] = make_uint2(r[4], r[5]);
-        }
-        return;
-    }
-
-    // rare: e == -127
+__device__ MM_TINY_INLINE void quantize_group_tiny(const uint32_t *__restrict__ v, uint8_t *__restrict__ out) {
     const float rs = __uint_as_float(254u << 23);  // 2^127
     uint32_t c[32];
 #pragma unroll
@@ -138,6 +80,77 @@ __device__ __forceinline__ void quantize_group(const uint16_t *__restrict__ row,
     }
 }
 
+// One 32-element group: gather (two bf16 per VGPR), block absmax, UE8M0 scale, convert, pack, store; returns the
+// scale byte.  `ix` holds BYTE offsets into the staged row (index << 1), two per register.
+// Conversion uses the CDNA4 MX converters (v_cvt_scalef32_pk_fp4_bf16 / _pk_fp8_bf16 / _pk32_bf6_bf16: dst =
+// RNE(src / scale), saturating) -- tests/test_hw_gpu.py checks them code-for-code against the oracle's encoders for every
+// finite bf16, and tests/test_quantize_gpu.py checks the kernel's bytes.
+template <int EL>
+__device__ __forceinline__ uint32_t quantize_group(const uint8_t *__restrict__ row, const uint32_t (&ix)[16],
+                                                   uint8_t *__restrict__ out) {
+    uint32_t v[16];  // v[i] = {element 2i (low half), element 2i+1 (high half)}
+    us2 amax2 = {0, 0};
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const uint32_t lo = *reinterpret_cast<const uint16_t *>(row + (ix[i] & 0xFFFFu));
+        const uint32_t hi = *reinterpret_cast<const uint16_t *>(row + (ix[i] >> 16));
+        v[i] = lo | (hi << 16);
+        const uint32_t mag = v[i] & 0x7FFF7FFFu;
+        us2 m;
+        __builtin_memcpy(&m, &mag, 4);
+        amax2 = __builtin_elementwise_max(amax2, m);
+    }
+    const uint32_t amax = amax2[0] > amax2[1] ? amax2[0] : amax2[1];
+    const int e = scale_exponent<EL>(amax << 16);
+    if (e == -127) {
+        quantize_group_tiny<EL>(v, out);
+        return 0u;
+    }
+    const float scale = __uint_as_float((uint32_t)(127 + e) << 23);  // 2^e, a normal fp32
+    if constexpr (EL == EL_FP8) {
+        uint32_t w[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            bf2 a, b;
+            __builtin_memcpy(&a, &v[2 * i], 4);
+            __builtin_memcpy(&b, &v[2 * i + 1], 4);
+            s2 r = {0, 0};
+            r = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(r, a, scale, false);
+            r = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(r, b, scale, true);
+            __builtin_memcpy(&w[i], &r, 4);
+        }
+        uint4 *o = reinterpret_cast<uint4 *>(out);
+        o[0] = make_uint4(w[0], w[1], w[2], w[3]);
+        o[1] = make_uint4(w[4], w[5], w[6], w[7]);
+    } else if constexpr (EL == EL_FP4) {
+        uint32_t w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            uint32_t r = 0;
+            bf2 a;
+            __builtin_memcpy(&a, &v[4 * i], 4);
+            r = __builtin_amdgcn_cvt_scalef32_pk_fp4_bf16(r, a, scale, 0);
+            __builtin_memcpy(&a, &v[4 * i + 1], 4);
+            r = __builtin_amdgcn_cvt_scalef32_pk_fp4_bf16(r, a, scale, 1);
+            __builtin_memcpy(&a, &v[4 * i + 2], 4);
+            r = __builtin_amdgcn_cvt_scalef32_pk_fp4_bf16(r, a, scale, 2);
+            __builtin_memcpy(&a, &v[4 * i + 3], 4);
+            r = __builtin_amdgcn_cvt_scalef32_pk_fp4_bf16(r, a, scale, 3);
+            w[i] = r;
+        }
+        *reinterpret_cast<uint4 *>(out) = make_uint4(w[0], w[1], w[2], w[3]);
+    } else {
+        bf32 x;
+        __builtin_memcpy(&x, v, 64);
+        const u6 r = __builtin_amdgcn_cvt_scalef32_pk32_bf6_bf16(x, scale);
+        uint2 *o = reinterpret_cast<uint2 *>(out);
+        o[0] = make_uint2(r[0], r[1]);
+        o[1] = make_uint2(r[2], r[3]);
+        o[2] = make_uint2(r[4], r[5]);
+    }
+    return (uint32_t)(e + 127);
+}
+
 template <bool W4, int MAXT>
 __global__ void __launch_bounds__(MAXT)
 reorder_quantize_kernel(const uint16_t *__restrict__ src, int rows, int K, const int16_t *__restrict__ idx, int KN,
@@ -155,10 +168,11 @@ reorder_quantize_kernel(const uint16_t *__restrict__ src, int rows, int K, const
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const uint4 q = p[i];
-            ix[4 * i] = q.x;
-            ix[4 * i + 1] = q.y;
-            ix[4 * i + 2] = q.z;
-            ix[4 * i + 3] = q.w;
+            // keep BYTE offsets (index << 1; indices are < 32768 so each half stays within 16 bits)
+            ix[4 * i] = (q.x << 1) & 0xFFFEFFFEu;
+            ix[4 * i + 1] = (q.y << 1) & 0xFFFEFFFEu;
+            ix[4 * i + 2] = (q.z << 1) & 0xFFFEFFFEu;
+            ix[4 * i + 3] = (q.w << 1) & 0xFFFEFFFEu;
         }
     }
     // Which segment this thread's group falls in (positions in reordered order).
@@ -199,20 +213,32 @@ reorder_quantize_kernel(const uint16_t *__restrict__ src, int rows, int K, const
             }
         }
         if (active) {
-            const uint16_t *row = reinterpret_cast<const uint16_t *>(smem);
+            const uint8_t *row = smem;
+            uint32_t byte;
+            uint8_t *sf;
             if (seg == 0) {
-                quantize_group<EL_FP4>(row, ix, oN + (size_t)r * (KN >> 1) + j * 16, sfN + sf_offset(r, j, kseg));
+                byte = quantize_group<EL_FP4>(row, ix, oN + (size_t)r * (KN >> 1) + j * 16);
+                sf = sfN;
             } else if (seg == 1) {
-                if constexpr (W4)
-                    quantize_group<EL_FP4>(row, ix, oS + (size_t)r * (KS >> 1) + j * 16, sfS + sf_offset(r, j, kseg));
-                else
-                    quantize_group<EL_FP6>(row, ix, oS + (size_t)r * (KS / 4 * 3) + j * 24, sfS + sf_offset(r, j, kseg));
+                if constexpr (W4) byte = quantize_group<EL_FP4>(row, ix, oS + (size_t)r * (KS >> 1) + j * 16);
+                else byte = quantize_group<EL_FP6>(row, ix, oS + (size_t)r * (KS / 4 * 3) + j * 24);
+                sf = sfS;
             } else {
-                if constexpr (W4)
-                    quantize_group<EL_FP4>(row, ix, oO + (size_t)r * (KO >> 1) + j * 16, sfO + sf_offset(r, j, kseg));
-                else
-                    quantize_group<EL_FP8>(row, ix, oO + (size_t)r * KO + j * 32, sfO + sf_offset(r, j, kseg));
+                if constexpr (W4) byte = quantize_group<EL_FP4>(row, ix, oO + (size_t)r * (KO >> 1) + j * 16);
+                else byte = quantize_group<EL_FP8>(row, ix, oO + (size_t)r * KO + j * 32);
+                sf = sfO;
             }
+            // the 4 block scales of one row and one 128-column slab are 4 consecutive bytes of the SF layout: gather them
+            // from the lane quad (segment widths are multiples of 128, so a quad never straddles segments) and store a dword
+#if (MM_QDBG & 2)
+            sf[sf_offset(r, j, kseg)] = (uint8_t)byte;
+#else
+            const uint32_t b1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)byte, 0x55, 0xF, 0xF, false);
+            const uint32_t b2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)byte, 0xAA, 0xF, 0xF, false);
+            const uint32_t b3 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)byte, 0xFF, 0xF, 0xF, false);
+            if ((g & 3) == 0)
+                *reinterpret_cast<uint32_t *>(sf + sf_offset(r, j, kseg)) = byte | (b1 << 8) | (b2 << 16) | (b3 << 24);
+#endif
         }
         __syncthreads();
         if (rn < rows) {
@@ -234,9 +260,20 @@ hipError_t launch_reorder_quantize(const void *src, int rows, int K, const int16
     const int stagers = K / 32;  // a row of K bf16 is staged as K/8 16-byte chunks, at most 4 per thread
     const int threads = ((G > stagers ? G : stagers) + 63) / 64 * 64;
     const size_t lds = (size_t)K * 2;
-    int blocks = rows < 256 * 8 ? rows : 256 * 8;
     auto kern = threads <= 256 ? (w4 ? reorder_quantize_kernel<true, 256> : reorder_quantize_kernel<false, 256>)
                                : (w4 ? reorder_quantize_kernel<true, 1024> : reorder_quantize_kernel<false, 1024>);
+    // one resident wave of workgroups (no tail), each striding over the rows
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kern), threads, lds) != hipSuccess ||
+        per_cu < 1)
+        per_cu = 1;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    int blocks = cus * per_cu;
+#if (MM_QDBG & 4)
+    blocks = 2048;
+#endif
+    blocks = rows < blocks ? rows : blocks;
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds, stream, (const uint16_t *)src, rows, K, idx, KN, KS, KO, oN,
                        oS, oO, sfN, sfS, sfO);
     return hipGetLastError();
