@@ -1,4 +1,5 @@
-"""Small fixed workload for the rocprofv3 --pmc passes: 5 x (reorder_quantize_x + matmul) on the bench shapes."""
+"""Small fixed workload for the rocprofv3 passes: N x (reorder_quantize_x + matmul) on the bench shape
+(4096^3, all-MXFP8 activations, w4 weights); `python tools/pmc_target.py mixed` adds the (2048,128,1920) split."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -7,9 +8,10 @@ import bench
 from micromix_amd import mixedgemm
 dev = torch.device("cuda:0")
 x, w, idx = [t.to(dev) for t in bench.synth_inputs()]
-for split in (bench.SPLIT, (2048, 128, 1920)):
+splits = [bench.SPLIT] + ([(2048, 128, 1920)] if "mixed" in sys.argv else [])
+for split in splits:
     b = mixedgemm.reorder_quantize_w4(w, idx, *split)
-    for _ in range(5):
+    for _ in range(10):
         a = mixedgemm.reorder_quantize_x(x, idx, *split)
         d = mixedgemm.matmul(a[0], b[0], a[1], b[1], a[2], b[2], a[3], b[3], a[4], b[4], a[5], b[5])
 torch.cuda.synchronize()
