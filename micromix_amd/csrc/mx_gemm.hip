@@ -315,7 +315,8 @@ static hipError_t launch_cfg(const GemmArgs &a, bool w4, hipStream_t stream) {
 
 hipError_t launch_mx_gemm(const GemmArgs &a, bool w4, hipStream_t stream) {
     if (a.M == 0 || a.N == 0) return hipSuccess;
-    if (a.M > 128) return launch_mx_gemm256(a, w4, stream);  // large-M path (mx_gemm256.hip)
+    if (a.M > 128) return launch_mx_gemm256(a, w4, stream);     // large-M path (mx_gemm256.hip)
+    if (a.M <= 64) return launch_mx_gemm_skinny(a, w4, stream);  // decode / small batch (mx_gemm_skinny.hip)
     return launch_cfg<Cfg<2, 2, 2, 2>>(a, w4, stream);
 }
 

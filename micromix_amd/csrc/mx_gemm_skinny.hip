@@ -1,0 +1,182 @@
+// Skinny (M <= 64) fused three-segment MX GEMM for gfx950: the decode / small-batch path of mm_matmul.
+//
+// Same arithmetic and reference citations as mx_gemm.hip (gemm.cu:26-78; per-segment bf16 rounding order of the chained
+// reference kernels).  At these token counts the product is bound by streaming the packed weights once from HBM
+// (N*K/2 bytes in the production MXFP4 weight mode), not by the MFMA, so the mapping is the opposite of the large-M kernel:
+//  * one workgroup = 32 output features x all tokens; its 8 waves split K between them (slab s goes to wave s % 8) and
+//    every wave streams its weight rows straight into registers -- no LDS staging, the operand is read exactly once
+//    (cdna_hip_programming.md: "GEMV / M <= 16 decode weights: load straight to VGPRs");
+//  * activations (M x K, a few hundred KB) and the scale-factor atoms are read by every wave from L2;
+//  * MFMA 32x32x64 with the tokens on the rows (padded to 32 or 64, rows past M read as zero through the buffer
+//    descriptor's range check) and the 32 features on the columns;
+//  * each wave keeps ONE accumulator set PER SEGMENT (16 registers per 32 tokens), the eight partial sums of a segment
+//    meet in LDS, and the chain D = bf16(N); D = bf16(S + D); D = bf16(O + D) is applied on the reduced values, so the
+//    reference's rounding order is reproduced exactly although K is split across waves.
+#include "mx_common.h"
+#include "mx_kernels.h"
+
+namespace mm {
+namespace skinny {
+
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+constexpr int NT = 512, NW = 8, BN = 32;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const uint8_t *base, unsigned bytes) {
+    const unsigned long long v = (unsigned long long)base;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    const unsigned nb = __builtin_amdgcn_readfirstlane(bytes);
+    return __builtin_amdgcn_make_buffer_rsrc((void *)(((unsigned long long)hi << 32) | lo), 0, (int)nb, 0x00020000);
+}
+
+template <int EL> struct G { static constexpr int BYTES = EL == EL_FP8 ? 128 : (EL == EL_FP6 ? 96 : 64); };
+
+// One lane's fragment for MFMA step h of slab `slab`: row byte offset `rowoff` inside the descriptor, kb = lane >> 5.
+// Register layouts as in mx_gemm256.hip (fp8: two 16-element halves; fp4/fp6: block 2h + kb).
+template <int EL>
+__device__ __forceinline__ v8i load_frag(__amdgpu_buffer_rsrc_t rsrc, int rowoff, int slab, int h, int kb) {
+    const int so = slab * G<EL>::BYTES;
+    v8i r = {0, 0, 0, 0, 0, 0, 0, 0};
+    if constexpr (EL == EL_FP8) {
+        const v4i lo = __builtin_amdgcn_raw_buffer_load_b128(rsrc, rowoff + (4 * h + kb) * 16, so, 0);
+        const v4i hi = __builtin_amdgcn_raw_buffer_load_b128(rsrc, rowoff + (4 * h + 2 + kb) * 16, so, 0);
+        r = v8i{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    } else if constexpr (EL == EL_FP4) {
+        const v4i v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, rowoff + (2 * h + kb) * 16, so, 0);
+        r = v8i{v[0], v[1], v[2], v[3], 0, 0, 0, 0};
+    } else {
+        typedef int v2i __attribute__((ext_vector_type(2)));
+        const int o = rowoff + (2 * h + kb) * 24;
+        const v2i a = __builtin_amdgcn_raw_buffer_load_b64(rsrc, o, so, 0);
+        const v2i b = __builtin_amdgcn_raw_buffer_load_b64(rsrc, o + 8, so, 0);
+        const v2i c = __builtin_amdgcn_raw_buffer_load_b64(rsrc, o + 16, so, 0);
+        r = v8i{a[0], a[1], b[0], b[1], c[0], c[1], 0, 0};
+    }
+    return r;
+}
+
+// One segment: this wave's share of the slabs (slab = wave, wave + 8, ...), accumulated into acc[TM].
+template <int XEL, int WEL, int TM>
+__device__ __forceinline__ void run_segment(v16f (&acc)[TM], const uint8_t *X, const uint8_t *W, const uint8_t *SFX,
+                                            const uint8_t *SFW, int nslab, int M, int N, int n0, int sfx_tiles, int sfw_tiles) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int li = lane & 31, kb = lane >> 5;
+    const int xrb = nslab * G<XEL>::BYTES, wrb = nslab * G<WEL>::BYTES;
+    int wrows = N - n0;
+    wrows = wrows > BN ? BN : wrows;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(X, (unsigned)M * (unsigned)xrb);
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(W + (size_t)n0 * wrb, (unsigned)wrows * (unsigned)wrb);
+    const __amdgpu_buffer_rsrc_t rsx = make_rsrc(SFX, (unsigned)sfx_tiles * (unsigned)nslab * 512u);
+    const __amdgpu_buffer_rsrc_t rsw = make_rsrc(SFW, (unsigned)sfw_tiles * (unsigned)nslab * 512u);
+    // scale dword of (row, slab): atom (row >> 7, slab) + (row & 31) * 16 + ((row >> 5) & 3) * 4
+    const int n = n0 + li;
+    const int sfw_off = (n >> 7) * nslab * 512 + (n & 31) * 16 + ((n >> 5) & 3) * 4;
+    int sfx_off[TM];
+#pragma unroll
+    for (int t = 0; t < TM; ++t) sfx_off[t] = li * 16 + t * 4;  // rows t*32 + li < 128: atom row-tile 0
+    const int sh = 8 * kb;
+
+#pragma unroll 2
+    for (int s = wave; s < nslab; s += NW) {
+        const int sw = __builtin_amdgcn_raw_buffer_load_b32(rsw, sfw_off, s * 512, 0) >> sh;
+        int sx[TM];
+        v8i xf[TM][2], wf[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) wf[h] = load_frag<WEL>(rw, li * wrb, s, h, kb);
+#pragma unroll
+        for (int t = 0; t < TM; ++t) {
+            sx[t] = __builtin_amdgcn_raw_buffer_load_b32(rsx, sfx_off[t], s * 512, 0) >> sh;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) xf[t][h] = load_frag<XEL>(rx, (t * 32 + li) * xrb, s, h, kb);
+        }
+#pragma unroll
+        for (int t = 0; t < TM; ++t) {
+            acc[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(xf[t][0], wf[0], acc[t], ElemTraits<XEL>::HW,
+                                                                    ElemTraits<WEL>::HW, 0, sx[t], 0, sw);
+            acc[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(xf[t][1], wf[1], acc[t], ElemTraits<XEL>::HW,
+                                                                    ElemTraits<WEL>::HW, 2, sx[t], 2, sw);
+        }
+    }
+}
+
+template <bool W4, int TM>
+__global__ void __launch_bounds__(NT) mx_gemm_skinny_kernel(GemmArgs a) {
+    __shared__ float red[NW][TM][16][64];
+    const int n0 = blockIdx.x * BN;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nseg[3] = {a.K[0] >> 7, a.K[1] >> 7, a.K[2] >> 7};
+
+    v16f accN[TM], accS[TM], accO[TM];
+#pragma unroll
+    for (int t = 0; t < TM; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) accN[t][i] = accS[t][i] = accO[t][i] = 0.0f;
+
+    if (nseg[0]) run_segment<EL_FP4, EL_FP4, TM>(accN, a.X[0], a.W[0], a.SFX[0], a.SFW[0], nseg[0], a.M, a.N, n0, a.sfx_row_tiles, a.sfw_row_tiles);
+    if (nseg[1]) run_segment<EL_FP6, (W4 ? EL_FP4 : EL_FP6), TM>(accS, a.X[1], a.W[1], a.SFX[1], a.SFW[1], nseg[1], a.M, a.N, n0, a.sfx_row_tiles, a.sfw_row_tiles);
+    if (nseg[2]) run_segment<EL_FP8, (W4 ? EL_FP4 : EL_FP8), TM>(accO, a.X[2], a.W[2], a.SFX[2], a.SFW[2], nseg[2], a.M, a.N, n0, a.sfx_row_tiles, a.sfw_row_tiles);
+
+    // cross-wave reduction, one segment at a time; thread `threadIdx.x` owns elements e = threadIdx.x + 512 * j of the
+    // TM x 16 x 64 accumulator image and carries the running D through the reference's rounding chain
+    constexpr int PER = TM * 16 * 64 / NT;  // 2 * TM
+    float run[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) run[j] = 0.0f;
+    bool any = false;
+    auto reduce = [&](const v16f (&acc)[TM]) {
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < TM; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) red[wave][t][i][lane] = acc[t][i];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const int e = threadIdx.x + NT * j;
+            float s = 0.0f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) s += (&red[w][0][0][0])[e];
+            s += run[j];
+            run[j] = a.round_per_segment ? bf16_bits_to_f32(f32_to_bf16_bits(s)) : s;
+        }
+        any = true;
+    };
+    if (nseg[0]) reduce(accN);
+    if (nseg[1]) reduce(accS);
+    if (nseg[2]) reduce(accO);
+    (void)any;
+
+    // element e = (t, i, l): token row t*32 + (i & 3) + 8 * (i >> 2) + 4 * (l >> 5), feature n0 + (l & 31)
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int e = threadIdx.x + NT * j;
+        const int l = e & 63, i = (e >> 6) & 15, t = e >> 10;
+        const int m = t * 32 + (i & 3) + 8 * (i >> 2) + 4 * (l >> 5);
+        const int n = n0 + (l & 31);
+        if (m < a.M && n < a.N) {
+            uint32_t b = f32_to_bf16_bits(run[j]);
+            if (a.bias != nullptr) b = f32_to_bf16_bits(bf16_bits_to_f32(b) + bf16_bits_to_f32(a.bias[n]));
+            a.D[(size_t)m * a.N + n] = (uint16_t)b;
+        }
+    }
+}
+
+}  // namespace skinny
+
+hipError_t launch_mx_gemm_skinny(const GemmArgs &a, bool w4, hipStream_t stream) {
+    using namespace skinny;
+    const int blocks = (a.N + BN - 1) / BN;
+    if (a.M <= 32) {
+        if (w4) hipLaunchKernelGGL((mx_gemm_skinny_kernel<true, 1>), dim3(blocks), dim3(NT), 0, stream, a);
+        else hipLaunchKernelGGL((mx_gemm_skinny_kernel<false, 1>), dim3(blocks), dim3(NT), 0, stream, a);
+    } else {
+        if (w4) hipLaunchKernelGGL((mx_gemm_skinny_kernel<true, 2>), dim3(blocks), dim3(NT), 0, stream, a);
+        else hipLaunchKernelGGL((mx_gemm_skinny_kernel<false, 2>), dim3(blocks), dim3(NT), 0, stream, a);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace mm

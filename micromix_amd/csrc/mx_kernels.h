@@ -25,5 +25,6 @@ hipError_t launch_reorder_quantize(const void *src, int rows, int K, const int16
                                    hipStream_t stream);
 hipError_t launch_mx_gemm(const GemmArgs &a, bool w4, hipStream_t stream);
 hipError_t launch_mx_gemm256(const GemmArgs &a, bool w4, hipStream_t stream);
+hipError_t launch_mx_gemm_skinny(const GemmArgs &a, bool w4, hipStream_t stream);
 
 }  // namespace mm
