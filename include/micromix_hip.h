@@ -96,6 +96,19 @@ int mm_reorder_quantize_gather(const void *src_bf16, int rows, int K_in, const i
                                mm_stream_t stream);
 
 /*
+ * Reorder-free quantizers (reference: mgemm/src/activate.cu:44-202, 208-500; bindings.cpp:307-387).  Natural column order,
+ * scale = amax > 1e-6 ? 2^ceil(log2(amax/FMAX)) : 1.0, a single RNE rounding from fp32.  Every SF buffer holds
+ * mm_sf_bytes_x(rows, Kseg) bytes (the reference sizes the weight variants that way too, bindings.cpp:348-350).
+ *   mm_activate_quantize : v = silu(A) * B, A and B [rows, KN+KS+KO] bf16 -> fp4 | fp6 | fp8   (activate_quantize_x)
+ *   mm_downproj_quantize : v = W;  mode MM_QUANT_MIXED -> fp4 | fp6 | fp8 (downproj_quantize_w),
+ *                                  mode MM_QUANT_W4    -> fp4 | fp4 | fp4 (downproj_quantize_w4)
+ */
+int mm_activate_quantize(const void *A_bf16, const void *B_bf16, int rows, int KN, int KS, int KO, uint8_t *oN, uint8_t *oS,
+                         uint8_t *oO, uint8_t *sfN, uint8_t *sfS, uint8_t *sfO, mm_stream_t stream);
+int mm_downproj_quantize(const void *W_bf16, int rows, int KN, int KS, int KO, int mode, uint8_t *oN, uint8_t *oS, uint8_t *oO,
+                         uint8_t *sfN, uint8_t *sfS, uint8_t *sfO, mm_stream_t stream);
+
+/*
  * Three-segment mixed-precision block-scaled GEMM:
  *   D[m,n] = bf16( sum over segments, blocks b:  2^(sfa[m,b]-127) * 2^(sfb[n,b]-127) * sum_{k in b} a[m,k]*b[n,k] ) (+ bias[n])
  *   A segments: AN [M,KN/2] fp4, AS [M,3KS/4] fp6(E3M2), AO [M,KO] fp8(E4M3)

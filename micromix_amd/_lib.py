@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("MICROMIX_HIP_LIB") or os.path.join(_PKG, "lib", "libm
 EXPORTS = (
     "mm_version", "mm_strerror", "mm_last_error",
     "mm_sf_bytes_x", "mm_sf_bytes_w", "mm_sf_offset",
-    "mm_reorder_quantize", "mm_reorder_quantize_gather", "mm_matmul",
+    "mm_reorder_quantize", "mm_reorder_quantize_gather", "mm_activate_quantize", "mm_downproj_quantize", "mm_matmul",
     "mm_diag_mfma", "mm_diag_hw_convert", "mm_diag_mfma_rate", "mm_diag_l2_bw", "mm_diag_set_clock_buffer",
 )
 
@@ -59,6 +59,10 @@ def load():
     lib.mm_reorder_quantize.argtypes = [vp, i, i, vp, i, i, i, i, vp, vp, vp, vp, vp, vp, vp]
     lib.mm_reorder_quantize_gather.restype = i
     lib.mm_reorder_quantize_gather.argtypes = [vp, i, i, vp, i, i, i, i, vp, vp, vp, vp, vp, vp, vp]
+    lib.mm_activate_quantize.restype = i
+    lib.mm_activate_quantize.argtypes = [vp, vp, i, i, i, i, vp, vp, vp, vp, vp, vp, vp]
+    lib.mm_downproj_quantize.restype = i
+    lib.mm_downproj_quantize.argtypes = [vp, i, i, i, i, i, vp, vp, vp, vp, vp, vp, vp]
     lib.mm_matmul.restype = i
     lib.mm_matmul.argtypes = [vp] * 12 + [i] * 7 + [vp, vp, vp]
     lib.mm_diag_mfma.restype = i

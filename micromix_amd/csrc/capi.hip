@@ -68,6 +68,29 @@ int mm_reorder_quantize_gather(const void *src_bf16, int rows, int K_in, const i
     return e == hipSuccess ? MM_OK : fail_hip(e, "mm_reorder_quantize_gather");
 }
 
+int mm_activate_quantize(const void *A_bf16, const void *B_bf16, int rows, int KN, int KS, int KO, uint8_t *oN, uint8_t *oS,
+                         uint8_t *oO, uint8_t *sfN, uint8_t *sfS, uint8_t *sfO, mm_stream_t stream) {
+    if (!split_ok(KN + KS + KO, KN, KS, KO)) return MM_ERR_BAD_SPLIT;
+    if (rows < 0) return MM_ERR_BAD_ARG;
+    if (rows == 0) return MM_OK;
+    if (!A_bf16 || !B_bf16) return MM_ERR_BAD_ARG;
+    if ((KN && (!oN || !sfN)) || (KS && (!oS || !sfS)) || (KO && (!oO || !sfO))) return MM_ERR_BAD_ARG;
+    hipError_t e = mm::launch_direct_quantize(A_bf16, B_bf16, rows, KN, KS, KO, 0, oN, oS, oO, sfN, sfS, sfO, (hipStream_t)stream);
+    return e == hipSuccess ? MM_OK : fail_hip(e, "mm_activate_quantize");
+}
+
+int mm_downproj_quantize(const void *W_bf16, int rows, int KN, int KS, int KO, int mode, uint8_t *oN, uint8_t *oS, uint8_t *oO,
+                         uint8_t *sfN, uint8_t *sfS, uint8_t *sfO, mm_stream_t stream) {
+    if (!split_ok(KN + KS + KO, KN, KS, KO)) return MM_ERR_BAD_SPLIT;
+    if (rows < 0 || (mode != MM_QUANT_MIXED && mode != MM_QUANT_W4)) return MM_ERR_BAD_ARG;
+    if (rows == 0) return MM_OK;
+    if (!W_bf16) return MM_ERR_BAD_ARG;
+    if ((KN && (!oN || !sfN)) || (KS && (!oS || !sfS)) || (KO && (!oO || !sfO))) return MM_ERR_BAD_ARG;
+    hipError_t e = mm::launch_direct_quantize(W_bf16, nullptr, rows, KN, KS, KO, mode == MM_QUANT_W4 ? 2 : 1, oN, oS, oO, sfN, sfS,
+                                              sfO, (hipStream_t)stream);
+    return e == hipSuccess ? MM_OK : fail_hip(e, "mm_downproj_quantize");
+}
+
 int mm_matmul(const uint8_t *AN, const uint8_t *BN, const uint8_t *AS, const uint8_t *BS, const uint8_t *AO,
               const uint8_t *BO, const uint8_t *SFAN, const uint8_t *SFBN, const uint8_t *SFAS, const uint8_t *SFBS,
               const uint8_t *SFAO, const uint8_t *SFBO, int M, int N, int KN, int KS, int KO, int wmode, int flags,

@@ -23,6 +23,8 @@ struct GemmArgs {
 hipError_t launch_reorder_quantize(const void *src, int rows, int K, const int16_t *idx, int KN, int KS, int KO, bool w4,
                                    uint8_t *oN, uint8_t *oS, uint8_t *oO, uint8_t *sfN, uint8_t *sfS, uint8_t *sfO,
                                    hipStream_t stream);
+hipError_t launch_direct_quantize(const void *A, const void *B, int rows, int KN, int KS, int KO, int mode, uint8_t *oN,
+                                  uint8_t *oS, uint8_t *oO, uint8_t *sfN, uint8_t *sfS, uint8_t *sfO, hipStream_t stream);
 hipError_t launch_mx_gemm(const GemmArgs &a, bool w4, hipStream_t stream);
 hipError_t launch_mx_gemm256(const GemmArgs &a, bool w4, hipStream_t stream);
 hipError_t launch_mx_gemm_skinny(const GemmArgs &a, bool w4, hipStream_t stream);

@@ -15,9 +15,10 @@ Differences from the reference, all deliberate:
     (bindings.cpp:134-148); bad splits still raise RuntimeError("Value error in run_...");
   * inputs are validated (dtype/device/contiguity) instead of being reinterpreted blindly;
   * `matmul` takes optional keyword-only `bias` and `rounding` arguments (extensions).
-The remaining exports of the reference module (rmsnorm_quantize_x, activate_quantize_x,
-downproj_quantize_w/_w4, FlashInfer KV ops) are outside the hot path; they raise
-NotImplementedError.
+    activate_quantize_x(A, B, KN, KS, KO)             -> (XN, XS, XO, SFXN, SFXS, SFXO)   (section 8f rank 1)
+    downproj_quantize_w / _w4 (W, KN, KS, KO)         -> (WN, WS, WO, SFWN, SFWS, SFWO)
+The remaining exports of the reference module (rmsnorm_quantize_x, FlashInfer KV ops) are outside
+the hot path; they raise NotImplementedError.
 """
 from __future__ import annotations
 
@@ -25,7 +26,8 @@ import torch
 
 from . import _lib
 
-__all__ = ["matmul", "reorder_quantize_x", "reorder_quantize_w", "reorder_quantize_w4"]
+__all__ = ["matmul", "reorder_quantize_x", "reorder_quantize_w", "reorder_quantize_w4", "activate_quantize_x",
+           "downproj_quantize_w", "downproj_quantize_w4"]
 
 
 def _stream_ptr(device) -> int:
@@ -198,6 +200,55 @@ def matmul(AN, BN, AS, BS, AO, BO, SFAN, SFBN, SFAS, SFBS, SFAO, SFBO, *, bias=N
     return out
 
 
+def _direct(src_a, src_b, KN, KS, KO, mode, what):
+    """shared body of activate_quantize_x / downproj_quantize_w / downproj_quantize_w4 (bindings.cpp:307-387)."""
+    lib = _lib.load()
+    srcs = (src_a,) if src_b is None else (src_a, src_b)
+    for t in srcs:
+        if not (isinstance(t, torch.Tensor) and t.is_cuda and _ok(t, torch.bfloat16, src_a.get_device())):
+            _check_tensor(t, "input", torch.bfloat16, src_a.device if isinstance(src_a, torch.Tensor) and src_a.is_cuda else None)
+    KN, KS, KO = int(KN), int(KS), int(KO)
+    if src_a.dim() != 2 or (src_b is not None and tuple(src_b.shape) != tuple(src_a.shape)):
+        raise RuntimeError("inputs must be 2-D [rows, K] of equal shape")
+    rows, K = src_a.shape
+    if KN < 0 or KS < 0 or KO < 0 or KN % 128 or KS % 128 or KO % 128 or KN + KS + KO != K:
+        _lib.check(_lib.MM_ERR_BAD_SPLIT, what)
+    dev = src_a.device
+    u8 = torch.uint8
+    w4 = mode == "w4"
+    oN = torch.empty((rows, KN // 2), dtype=u8, device=dev)
+    oS = torch.empty((rows, KS // 2 if w4 else KS // 4 * 3), dtype=u8, device=dev)
+    oO = torch.empty((rows, KO // 2 if w4 else KO), dtype=u8, device=dev)
+    sfN = torch.empty((_sf_bytes_x(rows, KN),), dtype=u8, device=dev)    # (rows/128+1)*128 rows for all three ops
+    sfS = torch.empty((_sf_bytes_x(rows, KS),), dtype=u8, device=dev)
+    sfO = torch.empty((_sf_bytes_x(rows, KO),), dtype=u8, device=dev)
+    with _on_device(dev.index):
+        if src_b is not None:
+            st = lib.mm_activate_quantize(_ptr(src_a), _ptr(src_b), rows, KN, KS, KO, _ptr(oN), _ptr(oS), _ptr(oO), _ptr(sfN),
+                                          _ptr(sfS), _ptr(sfO), _stream_ptr(dev))
+        else:
+            st = lib.mm_downproj_quantize(_ptr(src_a), rows, KN, KS, KO, _lib.MM_QUANT_W4 if w4 else _lib.MM_QUANT_MIXED,
+                                          _ptr(oN), _ptr(oS), _ptr(oO), _ptr(sfN), _ptr(sfS), _ptr(sfO), _stream_ptr(dev))
+    if st:
+        _lib.check(st, what)
+    return oN, oS, oO, sfN, sfS, sfO
+
+
+def activate_quantize_x(A, B, KN, KS, KO):
+    """bindings.cpp:307-335.  silu(A) * B, natural column order -> (XN, XS, XO, SFXN, SFXS, SFXO)."""
+    return _direct(A, B, KN, KS, KO, "x", "activate_quantize_x")
+
+
+def downproj_quantize_w(W, KN, KS, KO):
+    """bindings.cpp:336-362.  W [N,K] in natural column order -> fp4 | fp6 | fp8 segments."""
+    return _direct(W, None, KN, KS, KO, "w", "downproj_quantize_w")
+
+
+def downproj_quantize_w4(W, KN, KS, KO):
+    """bindings.cpp:363-387.  W [N,K] in natural column order -> three fp4 segments."""
+    return _direct(W, None, KN, KS, KO, "w4", "downproj_quantize_w4")
+
+
 def _not_on_path(name):
     def f(*a, **k):
         raise NotImplementedError(f"mixedgemm.{name} is outside the MX hot path built here (SURVEY.md section 8f)")
@@ -206,8 +257,5 @@ def _not_on_path(name):
 
 
 rmsnorm_quantize_x = _not_on_path("rmsnorm_quantize_x")
-activate_quantize_x = _not_on_path("activate_quantize_x")
-downproj_quantize_w = _not_on_path("downproj_quantize_w")
-downproj_quantize_w4 = _not_on_path("downproj_quantize_w4")
 for _n in ("batch_decode_i4", "batch_decode_f16", "init_kv_i4", "init_kv_f16", "append_kv_i4", "append_kv_f16"):
     globals()[_n] = _not_on_path(_n)

@@ -46,15 +46,25 @@ class QLinearLayer(nn.Module):
         self.BN, self.BS, self.BO, self.SFBN, self.SFBS, self.SFBO = quant(
             w, self.reorder_index, self.p4_num, self.p6_num, self.p8_num)
 
-    @torch.no_grad()
-    def forward(self, x):
+    def quantize_input(self, x):
+        """x [bsz, q_len, K] -> the 8-tuple (AN, AS, AO, SFAN, SFAS, SFAO, bsz, q_len) that `forward` also accepts.
+        Layers fed by the same tensor with the same reorder index (q/k/v, gate/up) can share one quantization, which
+        is what the reference's Mixtral caller does by hand (qMixtralLayer.py:289-295)."""
         bsz, q_len, _ = x.shape
         x = x.reshape(bsz * q_len, -1).contiguous()
-        AN, AS, AO, SFAN, SFAS, SFAO = mixedgemm.reorder_quantize_x(
-            x, self.reorder_index, self.p4_num, self.p6_num, self.p8_num)
+        return (*mixedgemm.reorder_quantize_x(x, self.reorder_index, self.p4_num, self.p6_num, self.p8_num), bsz, q_len)
+
+    @torch.no_grad()
+    def forward(self, x):
+        if isinstance(x, (tuple, list)):   # pre-quantized input (qMixtralLayer.py:292,359,509,517)
+            AN, AS, AO, SFAN, SFAS, SFAO, bsz, q_len = x
+            if AN.size(1) * 2 != self.p4_num or AO.size(1) != self.p8_num:
+                raise RuntimeError("pre-quantized input was produced with a different (p4, p6, p8) split")
+        else:
+            AN, AS, AO, SFAN, SFAS, SFAO, bsz, q_len = self.quantize_input(x)
         bias = self.bias
-        if bias is not None and bias.device != x.device:
-            bias = bias.to(x.device)
+        if bias is not None and bias.device != AN.device:
+            bias = bias.to(AN.device)
         y = mixedgemm.matmul(AN, self.BN, AS, self.BS, AO, self.BO, SFAN, self.SFBN, SFAS, self.SFBS, SFAO, self.SFBO,
                              bias=bias)
         return y.reshape(bsz, q_len, -1)

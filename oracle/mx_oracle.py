@@ -31,6 +31,7 @@ What each function follows (paths relative to /root/reference):
                                         mgemm/src/w4a4.cu:176 (beta=0), w4a6.cu:178 (beta=1)
 * matmul shape derivation + mode ..... mgemm/src/bindings.cpp:66-74,87
 * QLinearLayer wrapper ............... model/qLinearLayer.py:21-74
+* reorder-free quantizers ............ mgemm/src/activate.cu:29,44-202,208-500; bindings.cpp:307-387
 
 bf16 tensors are carried as ``uint16`` bit patterns so the oracle does not
 depend on torch.
@@ -289,6 +290,65 @@ def reorder_quantize(x_bits: np.ndarray, idx: np.ndarray, kn: int, ks: int, ko: 
         outs.append(np.ascontiguousarray(packed).reshape(rows, packed_width(fmt, kseg)))
         sfs.append(sf)
     return (*outs, *sfs)
+
+
+# --------------------------------------------------------------------------
+# reorder-free quantizers (activate.cu:44-202 silu(a)*b; :208-500 weights) -- SURVEY.md section 8f rank 1
+# --------------------------------------------------------------------------
+def scale_exponent_f32(amax: np.ndarray, fmt: str) -> np.ndarray:
+    """activate.cu:117-120: scale = amax > 1e-6 ? 2^ceil(log2(amax/FMAX)) : 1.0, with the exponent computed exactly
+    (smallest e with FMAX*2^e >= amax) and clamped to [-127, 127]; amax is an arbitrary fp32 here."""
+    fm, q = _FMAX_SPLIT[fmt]
+    a = np.ascontiguousarray(amax, dtype=np.float32)
+    bits = a.view(np.uint32).astype(np.int64)
+    exp = bits >> 23
+    e = exp - 127 - q + ((bits & 0x7FFFFF) > fm)
+    e = np.where(exp == 0, -127, e)
+    e = np.clip(e, -127, 127)
+    return np.where(a > np.float32(1e-6), e, 0).astype(np.int32)
+
+
+def silu_mul(a_bits: np.ndarray, b_bits: np.ndarray) -> np.ndarray:
+    """silu(float(a)) * float(b) in fp32, silu(x) = x / (1 + expf(-x))  (activate.cu:29,101)."""
+    a = bf16_to_f32(a_bits)
+    b = bf16_to_f32(b_bits)
+    with np.errstate(over="ignore"):
+        return ((a / (np.float32(1.0) + np.exp(-a, dtype=np.float32))) * b).astype(np.float32)
+
+
+def direct_quantize(v: np.ndarray, kn: int, ks: int, ko: int, w4: bool = False, sf_fill: int = 0):
+    """v [rows, K] fp32 in natural column order -> (ON, OS, OO, SFN, SFS, SFO); SF tensors sized sf_size_x."""
+    v = np.ascontiguousarray(v, dtype=np.float32)
+    rows, k = v.shape
+    check_split(k, kn, ks, ko)
+    fmts = ("fp4", "fp4", "fp4") if w4 else ("fp4", "fp6", "fp8")
+    outs, sfs = [], []
+    col = 0
+    for kseg, fmt in zip((kn, ks, ko), fmts):
+        g = v[:, col:col + kseg].reshape(rows, kseg // GROUP, GROUP)
+        col += kseg
+        amax = np.abs(g).max(axis=-1) if kseg else np.zeros((rows, 0), np.float32)
+        e = scale_exponent_f32(amax, fmt)
+        ec = np.maximum(e, -126)     # the kernel divides by a normal fp32 (2^-127 is subnormal)
+        fmax = FORMATS[fmt]["fmax"]
+        q = np.clip(g.astype(np.float64) * np.exp2(-ec.astype(np.float64))[..., None], -fmax, fmax).astype(np.float32)
+        codes = encode(q.reshape(rows, kseg), fmt)
+        sf = np.full((sf_size_x(rows, kseg),), sf_fill, dtype=np.uint8)
+        if kseg:
+            r = np.arange(rows)[:, None]
+            j = np.arange(kseg // 32)[None, :]
+            sf[sf_offset(r, j, kseg)] = (e + 127).astype(np.uint8)
+        outs.append(np.ascontiguousarray(_PACK[fmt](codes)).reshape(rows, packed_width(fmt, kseg)))
+        sfs.append(sf)
+    return (*outs, *sfs)
+
+
+def activate_quantize(a_bits, b_bits, kn, ks, ko):
+    return direct_quantize(silu_mul(a_bits, b_bits), kn, ks, ko, w4=False)
+
+
+def downproj_quantize(w_bits, kn, ks, ko, w4: bool):
+    return direct_quantize(bf16_to_f32(w_bits), kn, ks, ko, w4=w4)
 
 
 # --------------------------------------------------------------------------

@@ -66,8 +66,10 @@ def test_python_surface_matches_reference_signatures():
     for fn, first in ((mixedgemm.reorder_quantize_x, "X"), (mixedgemm.reorder_quantize_w, "W"),
                       (mixedgemm.reorder_quantize_w4, "W")):
         assert list(inspect.signature(fn).parameters) == [first, "reorder_index", "KN", "KS", "KO"]
-    for name in ("rmsnorm_quantize_x", "activate_quantize_x", "downproj_quantize_w", "downproj_quantize_w4",
-                 "batch_decode_i4", "init_kv_f16", "append_kv_i4"):
+    assert list(inspect.signature(mixedgemm.activate_quantize_x).parameters) == ["A", "B", "KN", "KS", "KO"]
+    assert list(inspect.signature(mixedgemm.downproj_quantize_w).parameters) == ["W", "KN", "KS", "KO"]
+    assert list(inspect.signature(mixedgemm.downproj_quantize_w4).parameters) == ["W", "KN", "KS", "KO"]
+    for name in ("rmsnorm_quantize_x", "batch_decode_i4", "init_kv_f16", "append_kv_i4"):
         with pytest.raises(NotImplementedError):
             getattr(mixedgemm, name)()
 

@@ -214,3 +214,23 @@ def test_golden_k14336_and_k5120():
         for n, a in zip(mg.QN, qx):
             assert np.array_equal(_sha(a), g[f"g4_{k}_x{n}_sha"])
         assert np.array_equal(mg.mm(qx, o.reorder_quantize(w4, i4, *split, "w4")), g[f"g4_{k}_d"])
+
+
+def test_direct_quantizers():
+    """reorder-free quantizers (activate.cu): empty block -> byte 127, exact scale rule on fp32 maxima, silu values."""
+    rows, k = 6, 384
+    w = lcg.bf16_normalish(77, (rows, k), exp_spread=5)
+    w[0, :32] = 0
+    n, s, ob, sfn, sfs, sfo = o.downproj_quantize(w, 128, 128, 128, w4=False)
+    assert sfn[int(o.sf_offset(0, 0, 128))] == 127 and n.shape == (rows, 64) and s.shape == (rows, 96) and ob.shape == (rows, 128)
+    # bf16 inputs: same bytes as the reorder quantizer with the identity index, except for the empty-block scale
+    ref = o.reorder_quantize(w, np.arange(k, dtype=np.int16), 128, 128, 128, "w")
+    assert np.array_equal(n, ref[0]) and np.array_equal(s, ref[1]) and np.array_equal(ob, ref[2])
+    w4 = o.downproj_quantize(w, 128, 128, 128, w4=True)
+    assert w4[1].shape == (rows, 64) and w4[2].shape == (rows, 64)
+    a = o.f32_to_bf16(np.array([[0.0, 1.0, -1.0, 8.0] * 32], np.float32))
+    b = o.f32_to_bf16(np.ones((1, 128), np.float32))
+    v = o.silu_mul(a, b)
+    assert abs(v[0, 1] - 0.7310586) < 1e-6 and abs(v[0, 2] + 0.26894143) < 1e-6 and v[0, 0] == 0
+    e = o.scale_exponent_f32(np.array([6.0, 6.0000005, 1e-7, 448.0, 3.0], np.float32), "fp4")
+    assert e.tolist() == [0, 1, 0, 7, -1]

@@ -33,3 +33,22 @@ def test_qlinear_forward_golden(dev):
         ulp = o.bf16_ulp_distance(got, g[key])
         assert (ulp > 1).mean() < 5e-3 and np.abs(o.bf16_to_f32(got) - o.bf16_to_f32(g[key])).max() < 0.25
         assert list(find_qlinear_layers(torch.nn.Sequential(q))) == ["0"]
+
+
+def test_prequantized_tuple_input(dev):
+    """qMixtralLayer.py:289-295 calling convention: one quantization shared by several projections."""
+    import torch
+    g = torch.Generator().manual_seed(1)
+    k, split = 512, (256, 128, 128)
+    x = torch.randn((2, 9, k), generator=g).to(torch.bfloat16).to(dev)
+    idx = torch.randperm(k, generator=g)
+    layers = []
+    for n in (256, 128):
+        lin = torch.nn.Linear(k, n, bias=False, dtype=torch.bfloat16)
+        layers.append(QLinearLayer(lin.to(dev), p8_num=split[2], p6_num=split[1], reorder_index=idx))
+    shared = layers[0].quantize_input(x)
+    assert len(shared) == 8 and shared[6:] == (2, 9)
+    for q in layers:
+        assert torch.equal(q(shared), q(x))
+    with pytest.raises(RuntimeError, match="different"):
+        QLinearLayer(torch.nn.Linear(k, 128, bias=False, dtype=torch.bfloat16).to(dev), p8_num=256, p6_num=128, reorder_index=idx)(shared)
