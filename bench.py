@@ -183,7 +183,7 @@ def main():
             "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_TFLOPS_FP8, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_TFLOPS_FP8, 4),
             "traffic": traffic.get("hbm_bytes_per_launch") if traffic else None,
-            "kernel": "mm::mx_gemm_kernel (fused three-segment scaled-MFMA GEMM)",
+            "kernel": "mm::g256::mx_gemm256_kernel<true,false> (fused three-segment scaled-MFMA GEMM, 256x256 tiles)",
             "kernel_us": round(kern_ms * 1e3, 2), "algorithmic_flop_per_launch": flop,
             "algorithmic_bytes_per_launch": M * K + N * K // 2 + (M + N) * K // 32 + 2 * M * N,
             "note": "peak = dense fp8-operand scaled-MFMA rate; A is fp8 so the fp8 rate applies to the whole launch",

@@ -57,7 +57,9 @@ enum mm_weight_mode {
 enum mm_matmul_flags {
     MM_ROUND_PER_SEGMENT = 0, /* default: accumulator rounded through bf16 after each segment, as the
                                  reference's three chained kernels do (gemm.cu:75-77) */
-    MM_ROUND_ONCE = 1         /* single fp32 accumulator across segments, one bf16 rounding */
+    MM_ROUND_ONCE = 1,        /* single fp32 accumulator across segments, one bf16 rounding */
+    MM_SPLIT_K_ALWAYS = 2     /* mm_matmul_ws: split K whenever the shape allows it, not only where the cost model expects a
+                                 gain (tests and tuning) */
 };
 
 int mm_version(void);
@@ -121,6 +123,20 @@ int mm_matmul(const uint8_t *AN, const uint8_t *BN, const uint8_t *AS, const uin
               const uint8_t *BO, const uint8_t *SFAN, const uint8_t *SFBN, const uint8_t *SFAS, const uint8_t *SFBS,
               const uint8_t *SFAO, const uint8_t *SFBO, int M, int N, int KN, int KS, int KO, int wmode, int flags,
               const void *bias_bf16, void *D_bf16, mm_stream_t stream);
+
+/*
+ * mm_matmul with a caller-owned scratch buffer.  For shapes with few output tiles (medium M or small N; M > 64) the GEMM
+ * splits K across workgroups, which needs room for fp32 partial sums; the library never allocates, so the caller passes
+ *   workspace        device buffer of at least mm_matmul_workspace_bytes(...) bytes, 16-byte aligned, not shared with a
+ *                    call that may run concurrently on another stream (NULL or too small: same results, without the split)
+ * mm_matmul_workspace_bytes returns 0 when the shape would not be split.  Results are deterministic either way; they differ
+ * from the unsplit kernel only in fp32 summation order (the bf16 rounding chain of MM_ROUND_PER_SEGMENT is kept).
+ */
+size_t mm_matmul_workspace_bytes(int M, int N, int KN, int KS, int KO, int wmode, int flags);
+int mm_matmul_ws(const uint8_t *AN, const uint8_t *BN, const uint8_t *AS, const uint8_t *BS, const uint8_t *AO,
+                 const uint8_t *BO, const uint8_t *SFAN, const uint8_t *SFBN, const uint8_t *SFAS, const uint8_t *SFBS,
+                 const uint8_t *SFAO, const uint8_t *SFBO, int M, int N, int KN, int KS, int KO, int wmode, int flags,
+                 const void *bias_bf16, void *D_bf16, void *workspace, size_t workspace_bytes, mm_stream_t stream);
 
 /*
  * Hardware diagnostics (not on the product path; used by the GPU tests to pin register

@@ -17,13 +17,14 @@ EXPORTS = (
     "mm_version", "mm_strerror", "mm_last_error",
     "mm_sf_bytes_x", "mm_sf_bytes_w", "mm_sf_offset",
     "mm_reorder_quantize", "mm_reorder_quantize_gather", "mm_activate_quantize", "mm_downproj_quantize", "mm_matmul",
+    "mm_matmul_ws", "mm_matmul_workspace_bytes",
     "mm_diag_mfma", "mm_diag_hw_convert", "mm_diag_mfma_rate", "mm_diag_l2_bw", "mm_diag_set_clock_buffer",
 )
 
 MM_OK, MM_ERR_BAD_SPLIT, MM_ERR_BAD_ARG, MM_ERR_LAUNCH, MM_ERR_UNSUPPORTED, MM_ERR_NO_DEVICE = range(6)
 MM_QUANT_MIXED, MM_QUANT_W4 = 0, 1
 MM_W_MATCH, MM_W_FP4 = 0, 1
-MM_ROUND_PER_SEGMENT, MM_ROUND_ONCE = 0, 1
+MM_ROUND_PER_SEGMENT, MM_ROUND_ONCE, MM_SPLIT_K_ALWAYS = 0, 1, 2
 
 _lib = None
 
@@ -65,6 +66,10 @@ def load():
     lib.mm_downproj_quantize.argtypes = [vp, i, i, i, i, i, vp, vp, vp, vp, vp, vp, vp]
     lib.mm_matmul.restype = i
     lib.mm_matmul.argtypes = [vp] * 12 + [i] * 7 + [vp, vp, vp]
+    lib.mm_matmul_ws.restype = i
+    lib.mm_matmul_ws.argtypes = [vp] * 12 + [i] * 7 + [vp, vp, vp, ctypes.c_size_t, vp]
+    lib.mm_matmul_workspace_bytes.restype = ctypes.c_size_t
+    lib.mm_matmul_workspace_bytes.argtypes = [i] * 7
     lib.mm_diag_mfma.restype = i
     lib.mm_diag_mfma.argtypes = [i, i, i, i, vp, vp, vp, vp, vp, vp]
     lib.mm_diag_hw_convert.restype = i

@@ -91,10 +91,25 @@ int mm_downproj_quantize(const void *W_bf16, int rows, int KN, int KS, int KO, i
     return e == hipSuccess ? MM_OK : fail_hip(e, "mm_downproj_quantize");
 }
 
+size_t mm_matmul_workspace_bytes(int M, int N, int KN, int KS, int KO, int wmode, int flags) {
+    (void)wmode;
+    if (M <= 0 || N <= 0 || KN < 0 || KS < 0 || KO < 0 || (KN % 128) || (KS % 128) || (KO % 128)) return 0;
+    const int K[3] = {KN, KS, KO};
+    return mm::mx_gemm_workspace_bytes(M, N, K, (flags & MM_SPLIT_K_ALWAYS) != 0);
+}
+
 int mm_matmul(const uint8_t *AN, const uint8_t *BN, const uint8_t *AS, const uint8_t *BS, const uint8_t *AO,
               const uint8_t *BO, const uint8_t *SFAN, const uint8_t *SFBN, const uint8_t *SFAS, const uint8_t *SFBS,
               const uint8_t *SFAO, const uint8_t *SFBO, int M, int N, int KN, int KS, int KO, int wmode, int flags,
               const void *bias_bf16, void *D_bf16, mm_stream_t stream) {
+    return mm_matmul_ws(AN, BN, AS, BS, AO, BO, SFAN, SFBN, SFAS, SFBS, SFAO, SFBO, M, N, KN, KS, KO, wmode, flags, bias_bf16,
+                        D_bf16, nullptr, 0, stream);
+}
+
+int mm_matmul_ws(const uint8_t *AN, const uint8_t *BN, const uint8_t *AS, const uint8_t *BS, const uint8_t *AO,
+                 const uint8_t *BO, const uint8_t *SFAN, const uint8_t *SFBN, const uint8_t *SFAS, const uint8_t *SFBS,
+                 const uint8_t *SFAO, const uint8_t *SFBO, int M, int N, int KN, int KS, int KO, int wmode, int flags,
+                 const void *bias_bf16, void *D_bf16, void *workspace, size_t workspace_bytes, mm_stream_t stream) {
     if (M < 0 || N < 0 || KN < 0 || KS < 0 || KO < 0) return MM_ERR_BAD_ARG;
     if ((KN % 128) || (KS % 128) || (KO % 128)) return MM_ERR_BAD_SPLIT;
     if (wmode != MM_W_MATCH && wmode != MM_W_FP4) return MM_ERR_BAD_ARG;
@@ -120,6 +135,11 @@ int mm_matmul(const uint8_t *AN, const uint8_t *BN, const uint8_t *AS, const uin
     a.bias = (const uint16_t *)bias_bf16;
     a.D = (uint16_t *)D_bf16;
     a.clock_out = g_clock_buf;
+    a.ws = (float *)workspace;
+    a.ws_bytes = workspace ? workspace_bytes : 0;
+    a.splits = 0;
+    a.force_split = (flags & MM_SPLIT_K_ALWAYS) ? 1 : 0;
+    a.split_first[0] = a.split_first[1] = a.split_first[2] = a.split_first[3] = 0;
     hipError_t e = mm::launch_mx_gemm(a, wmode == MM_W_FP4, (hipStream_t)stream);
     return e == hipSuccess ? MM_OK : fail_hip(e, "mm_matmul");
 }

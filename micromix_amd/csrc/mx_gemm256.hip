@@ -1,7 +1,7 @@
 // 256x256-tile fused three-segment MX GEMM for gfx950 -- the large-M path of mm_matmul.
 //
-// Same arithmetic as mx_gemm.hip (see there for the reference citations: gemm.cu:26-78, w4a4.cu,
-// w4a6.cu, w4a8.cu, w6a6.cu, w8a8.cu); different machine mapping, chosen from measurements on MI355X
+// Arithmetic and reference citations: see mx_gemm.hip (gemm.cu:26-78, w4a4.cu, w4a6.cu, w4a8.cu, w6a6.cu,
+// w8a8.cu).  Machine mapping, chosen from measurements on MI355X
 // (tools/mfma_rate.py, profiles/):
 //  * v_mfma_scale_f32_32x32x64_f8f6f4 sustains ~3.9 PF with the fp8 operand as srcA but only ~3.0-3.5 PF
 //    with it as srcB, and fp6(A) x fp4(B) beats fp4(A) x fp6(B) the same way.  Activations are the wider
@@ -22,6 +22,7 @@
 //    fragments are already in registers.
 //  * with tokens on MFMA rows the accumulator has the feature index on the lane, so the epilogue transposes
 //    each wave's tile through LDS (free at that point) and stores whole 256-byte rows.
+#include <math.h>
 #include <stdlib.h>
 #include <type_traits>
 
@@ -57,6 +58,112 @@ namespace mm {
 #undef MM_TM
 
 
+// ---------------------------------------------------------------------------------------------------------
+// split-K for shapes with few tiles (medium M, or small N): 128 x 256 tiles x `splits` workgroups, each on a slab range
+// of one segment, raw fp32 partial sums in the caller's workspace, then a reduction kernel that adds them in split
+// order (deterministic) and applies the reference's rounding chain D = bf16(N); D = bf16(S + D); D = bf16(O + D).
+// ---------------------------------------------------------------------------------------------------------
+constexpr int SPLIT_WG_FLOATS = g128::NACC * g128::NT;  // 32768 floats = 128 KiB of partial sums per workgroup
+
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(GemmArgs a, int tiles_n, int total) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    // e = (tile, accumulator register r, thread tid of the GEMM workgroup): consecutive threads read consecutive floats
+    const int tid = e & (g128::NT - 1), r = (e >> 9) & (g128::NACC - 1), tile = e >> 15;
+    const float *p = a.ws + ((size_t)tile * a.splits * g128::NACC + r) * g128::NT + tid;
+    float run = 0.0f;
+#pragma unroll
+    for (int seg = 0; seg < 3; ++seg) {
+        if (a.split_first[seg + 1] == a.split_first[seg]) continue;
+        float s = 0.0f;
+        for (int q = a.split_first[seg]; q < a.split_first[seg + 1]; ++q) s += p[(size_t)q * SPLIT_WG_FLOATS];
+        s += run;
+        run = a.round_per_segment ? bf16_bits_to_f32(f32_to_bf16_bits(s)) : s;
+    }
+    // accumulator layout of the tile kernel: wave = 2 * wm + wn owns tokens wm*32.., features wn*128..; register r of
+    // MFMA tile tn = r >> 4: token (r & 3) + 8 * ((r >> 2) & 3) + 4 * (lane >> 5), feature tn*32 + (lane & 31)
+    const int wave = tid >> 6, lane = tid & 63, wm = wave >> 1, wn = wave & 1;
+    const int m = (tile / tiles_n) * g128::BM + wm * 32 + (r & 3) + 8 * ((r >> 2) & 3) + 4 * (lane >> 5);
+    const int n = (tile % tiles_n) * g128::BN + wn * 128 + (r >> 4) * 32 + (lane & 31);
+    if (m < a.M && n < a.N) {
+        uint32_t b = f32_to_bf16_bits(run);
+        if (a.bias != nullptr) b = f32_to_bf16_bits(bf16_bits_to_f32(b) + bf16_bits_to_f32(a.bias[n]));
+        a.D[(size_t)m * a.N + n] = (uint16_t)b;
+    }
+}
+
+static int env_int(const char *name, int dflt) {
+    const char *v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
+// Number of K splits for (M, N, K) and the segment each split works on; 0 = do not split.
+// Cost model fitted to MI355X measurements (tools/bench_shapes.py): a workgroup of a launch with few tiles walks one
+// 128-deep slab in ~0.7 us (DMA-latency bound), and every split adds tiles * 128 KiB of fp32 partial sums that are
+// written and read back at ~4 TB/s (0.064 us per tile and split), plus ~5 us for the second launch:
+//     t(S) = 0.7 * slabs / S + 0.064 * tiles * S (+ 5)   ->   S* = 3.3 * sqrt(slabs / tiles)
+// Split only when that beats the unsplit 0.7 * slabs by 15 %.  `force` (MM_SPLIT_K_ALWAYS, tests and tuning) skips the
+// model.  MICROMIX_SPLITK=0 disables splitting, =S pins the split count.
+static int plan_splits(int M, int N, const int K[3], bool force, int first[4]) {
+    static const int pinned = env_int("MICROMIX_SPLITK", -1);
+    if (pinned == 0 || M <= 64) return 0;
+    const int tiles = ((M + g128::BM - 1) / g128::BM) * ((N + g128::BN - 1) / g128::BN);
+    int n[3], total = 0, nonempty = 0;
+    for (int i = 0; i < 3; ++i) {
+        n[i] = K[i] >> 7;
+        total += n[i];
+        nonempty += n[i] > 0;
+    }
+    int cap = 256 / tiles;          // one wave of workgroups on the 256 CUs
+    cap = cap > 16 ? 16 : cap;
+    cap = cap > total / 2 ? total / 2 : cap;  // at least two slabs per split on average
+    if (cap < 2 || cap < nonempty) return 0;
+    int S;
+    if (pinned > 0 || force) {
+        S = pinned > 0 ? pinned : cap;
+    } else {
+        S = (int)(3.3f * sqrtf((float)total / (float)tiles) + 0.5f);
+        S = S < nonempty ? nonempty : S;
+        S = S > cap ? cap : S;
+        const float unsplit = 0.7f * total, split = 0.7f * total / S + 0.064f * tiles * S + 5.0f;
+        if (S < 2 || split > 0.85f * unsplit) return 0;
+    }
+    S = S > cap ? cap : S;
+    if (S < 2 || S < nonempty) return 0;
+    // segments get splits in proportion to their slab counts, at least one each and never more than their slabs
+    int parts[3], used = 0;
+    for (int i = 0; i < 3; ++i) {
+        parts[i] = n[i] ? (S * n[i]) / total : 0;
+        if (n[i] && parts[i] == 0) parts[i] = 1;
+        used += parts[i];
+    }
+    while (used != S) {
+        int best = -1;
+        for (int i = 0; i < 3; ++i) {
+            if (!n[i]) continue;
+            if (used < S) {  // give a split to the segment with the longest slab run per split
+                if (parts[i] < n[i] && (best < 0 || n[i] * parts[best] > n[best] * parts[i])) best = i;
+            } else {         // take one from the segment with the shortest
+                if (parts[i] > 1 && (best < 0 || n[i] * parts[best] < n[best] * parts[i])) best = i;
+            }
+        }
+        if (best < 0) break;
+        parts[best] += used < S ? 1 : -1;
+        used += used < S ? 1 : -1;
+    }
+    first[0] = 0;
+    for (int i = 0; i < 3; ++i) first[i + 1] = first[i] + parts[i];
+    return first[3];
+}
+
+size_t mx_gemm_workspace_bytes(int M, int N, const int K[3], bool force) {
+    int first[4];
+    const int S = plan_splits(M, N, K, force, first);
+    if (S == 0) return 0;
+    const size_t tiles = (size_t)((M + g128::BM - 1) / g128::BM) * ((N + g128::BN - 1) / g128::BN);
+    return tiles * S * SPLIT_WG_FLOATS * sizeof(float);
+}
+
 template <class KernelT>
 static hipError_t launch_tile(KernelT kern, bool &attr_done, int lds_bytes, int tiles, int threads, const GemmArgs &a,
                               hipStream_t stream) {
@@ -70,23 +177,31 @@ static hipError_t launch_tile(KernelT kern, bool &attr_done, int lds_bytes, int 
 }
 
 hipError_t launch_mx_gemm256(const GemmArgs &a, bool w4, hipStream_t stream) {
-    static bool done[4] = {false, false, false, false};
+    static bool done[6] = {false, false, false, false, false, false};
     const int tn = (a.N + 255) / 256;
     const int tiles256 = ((a.M + 255) / 256) * tn, tiles128 = ((a.M + 127) / 128) * tn;
+    if (a.ws != nullptr) {
+        GemmArgs b = a;
+        b.splits = plan_splits(a.M, a.N, a.K, a.force_split != 0, b.split_first);
+        if (b.splits && (size_t)tiles128 * b.splits * SPLIT_WG_FLOATS * sizeof(float) <= a.ws_bytes) {
+            hipError_t e = w4 ? launch_tile(g128::mx_gemm256_kernel<true, true>, done[4], g128::Lds<true>::TOTAL, tiles128 * b.splits, g128::NT, b, stream)
+                              : launch_tile(g128::mx_gemm256_kernel<false, true>, done[5], g128::Lds<false>::TOTAL, tiles128 * b.splits, g128::NT, b, stream);
+            if (e != hipSuccess) return e;
+            const int total = tiles128 * SPLIT_WG_FLOATS;
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, b, tn, total);
+            return hipGetLastError();
+        }
+    }
     // 256-row tiles move the fewest L2->LDS bytes per flop; use them when they (nearly) fill the 256 CUs, otherwise halve
     // the tile height so that twice as many workgroups exist.
-    static int force = -1;
-    if (force < 0) {
-        const char *env = getenv("MICROMIX_GEMM_TILE");   // kernel-developer override: 256 or 128
-        force = env ? atoi(env) : 0;
-    }
+    static const int force = env_int("MICROMIX_GEMM_TILE", 0);   // kernel-developer override: 256 or 128
     const bool use128 = force == 128 || (force != 256 && tiles256 < 192);
     if (!use128) {
-        if (w4) return launch_tile(g256::mx_gemm256_kernel<true>, done[0], g256::Lds<true>::TOTAL, tiles256, g256::NT, a, stream);
-        return launch_tile(g256::mx_gemm256_kernel<false>, done[1], g256::Lds<false>::TOTAL, tiles256, g256::NT, a, stream);
+        if (w4) return launch_tile(g256::mx_gemm256_kernel<true, false>, done[0], g256::Lds<true>::TOTAL, tiles256, g256::NT, a, stream);
+        return launch_tile(g256::mx_gemm256_kernel<false, false>, done[1], g256::Lds<false>::TOTAL, tiles256, g256::NT, a, stream);
     }
-    if (w4) return launch_tile(g128::mx_gemm256_kernel<true>, done[2], g128::Lds<true>::TOTAL, tiles128, g128::NT, a, stream);
-    return launch_tile(g128::mx_gemm256_kernel<false>, done[3], g128::Lds<false>::TOTAL, tiles128, g128::NT, a, stream);
+    if (w4) return launch_tile(g128::mx_gemm256_kernel<true, false>, done[2], g128::Lds<true>::TOTAL, tiles128, g128::NT, a, stream);
+    return launch_tile(g128::mx_gemm256_kernel<false, false>, done[3], g128::Lds<false>::TOTAL, tiles128, g128::NT, a, stream);
 }
 
 }  // namespace mm

@@ -17,6 +17,11 @@ struct GemmArgs {
     int round_per_segment;
     const uint16_t *bias;   // optional [N] bf16
     uint16_t *D;            // [M, N] bf16
+    float *ws;              // split-K workspace (NULL: never split), see mm_matmul_ws
+    size_t ws_bytes;
+    int force_split;        // MM_SPLIT_K_ALWAYS
+    int splits;             // filled in by the launcher when it splits K
+    int split_first[4];     // splits [split_first[i], split_first[i+1]) work on segment i
     unsigned long long *clock_out;  // diagnostics only (mm_diag_set_clock_buffer): per workgroup {shader cycles, 100 MHz ticks}
 };
 
@@ -28,5 +33,6 @@ hipError_t launch_direct_quantize(const void *A, const void *B, int rows, int KN
 hipError_t launch_mx_gemm(const GemmArgs &a, bool w4, hipStream_t stream);
 hipError_t launch_mx_gemm256(const GemmArgs &a, bool w4, hipStream_t stream);
 hipError_t launch_mx_gemm_skinny(const GemmArgs &a, bool w4, hipStream_t stream);
+size_t mx_gemm_workspace_bytes(int M, int N, const int K[3], bool force);  // 0 when mm_matmul would not split K for this shape
 
 }  // namespace mm

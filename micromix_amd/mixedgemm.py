@@ -137,8 +137,14 @@ def reorder_quantize_w4(W, reorder_index, KN, KS, KO):
     return _quantize(W, reorder_index, KN, KS, KO, "w4", "reorder_quantize_w4")
 
 
-def matmul(AN, BN, AS, BS, AO, BO, SFAN, SFBN, SFAS, SFBS, SFAO, SFBO, *, bias=None, rounding="reference", out=None):
+def matmul(AN, BN, AS, BS, AO, BO, SFAN, SFBN, SFAS, SFBS, SFAO, SFBO, *, bias=None, rounding="reference", out=None,
+           split_k=True):
     """bindings.cpp:50-102.  Returns a new [M, N] bf16 tensor.
+
+    Keyword-only extras (not in the reference): `bias` [N] bf16 fused into the epilogue, `rounding` "reference" (bf16 after
+    each segment, as the chained reference kernels) or "fused", `out` to write into an existing tensor, `split_k=False`
+    to forbid the K-split the library uses for shapes with few output tiles (it needs a scratch tensor; "force" splits
+    wherever the shape allows, for tests).
 
     Shapes are derived exactly as the reference does (bindings.cpp:66-70) and the weight mode
     from `AS.size(1) == BS.size(1) and AO.size(1) == BO.size(1)` (bindings.cpp:74,87).
@@ -191,10 +197,20 @@ def matmul(AN, BN, AS, BS, AO, BO, SFAN, SFBN, SFAS, SFBS, SFAO, SFBO, *, bias=N
             _check_tensor(out, "out", torch.bfloat16, dev)
         if out.dim() != 2 or out.size(0) != M or out.size(1) != N:
             raise RuntimeError("out has the wrong shape")
+    # shapes with few output tiles split K and need scratch for fp32 partial sums; it comes from torch's caching allocator
+    # (stream-ordered, graph-capture safe) because the C ABI never allocates
+    ws, ws_bytes = None, 0
+    if split_k and M > 64:
+        if split_k == "force":
+            flags |= _lib.MM_SPLIT_K_ALWAYS
+        ws_bytes = lib.mm_matmul_workspace_bytes(M, N, KN, KS, KO, wmode, flags)
+        if ws_bytes:
+            ws = torch.empty((ws_bytes,), dtype=u8, device=dev)
     with _on_device(index):
-        st = lib.mm_matmul(_ptr(AN), _ptr(BN), _ptr(AS), _ptr(BS), _ptr(AO), _ptr(BO), _ptr(SFAN), _ptr(SFBN),
-                           _ptr(SFAS), _ptr(SFBS), _ptr(SFAO), _ptr(SFBO), M, N, KN, KS, KO, wmode, flags,
-                           _ptr(bias) if bias is not None else None, _ptr(out), _stream_ptr(dev))
+        st = lib.mm_matmul_ws(_ptr(AN), _ptr(BN), _ptr(AS), _ptr(BS), _ptr(AO), _ptr(BO), _ptr(SFAN), _ptr(SFBN),
+                              _ptr(SFAS), _ptr(SFBS), _ptr(SFAO), _ptr(SFBO), M, N, KN, KS, KO, wmode, flags,
+                              _ptr(bias) if bias is not None else None, _ptr(out), _ptr(ws) if ws is not None else None,
+                              ws_bytes, _stream_ptr(dev))
     if st:
         _lib.check(st, "matmul")
     return out

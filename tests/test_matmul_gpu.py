@@ -43,6 +43,12 @@ SHAPES = [
     (130, 256, 4096, (2048, 1024, 1024)), (257, 512, 1024, (0, 0, 1024)), (64, 200, 512, (256, 0, 256)),
     (300, 1024, 2048, (1024, 0, 1024)), (96, 640, 5120, (4096, 512, 512)),
 ]
+# shapes the library runs as split-K when given a workspace (few output tiles, M > 64); each also runs unsplit
+SPLIT_SHAPES = [
+    (65, 256, 512, (0, 0, 512)), (130, 256, 4096, (2048, 1024, 1024)), (128, 1024, 4096, (0, 0, 4096)),
+    (256, 512, 1792, (1024, 128, 640)), (200, 300, 2048, (128, 1792, 128)), (512, 2048, 1024, (512, 512, 0)),
+    (96, 640, 5120, (4096, 512, 512)), (192, 256, 14336, (12288, 1024, 1024)), (129, 264, 768, (256, 256, 256)),
+]
 
 
 @pytest.mark.parametrize("wmode", ("w4", "w"))
@@ -53,6 +59,33 @@ def test_matmul_matches_oracle(dev, wmode, rounding, m, n, k, split):
     qx, qw = quantized(rng, m, n, k, split, wmode)
     got = gpu_matmul(dev, qx, qw, rounding=rounding)
     check_gemm(got, qx, qw, rounding, label=f"{m}x{n}x{k} {split} {wmode} {rounding}")
+
+
+@pytest.mark.parametrize("wmode", ("w4", "w"))
+@pytest.mark.parametrize("rounding", ("reference", "fused"))
+@pytest.mark.parametrize("m,n,k,split", SPLIT_SHAPES)
+def test_split_k_matches_oracle(dev, wmode, rounding, m, n, k, split):
+    """the K-split path (partial sums in a workspace + reduction kernel) and the unsplit kernels on the same inputs"""
+    from micromix_amd import _lib
+    rng = np.random.default_rng(m * 5 + n * 11 + k)
+    qx, qw = quantized(rng, m, n, k, split, wmode)
+    assert _lib.load().mm_matmul_workspace_bytes(m, n, *split, 1 if wmode == "w4" else 0, _lib.MM_SPLIT_K_ALWAYS) > 0
+    for split_k in ("force", True, False):
+        got = gpu_matmul(dev, qx, qw, rounding=rounding, split_k=split_k)
+        check_gemm(got, qx, qw, rounding, label=f"{m}x{n}x{k} {split} {wmode} {rounding} split_k={split_k}")
+
+
+def test_split_k_is_deterministic_and_keeps_bias(dev):
+    import torch
+    rng = np.random.default_rng(77)
+    m, n, k, split = 160, 512, 2048, (1024, 256, 768)
+    qx, qw = quantized(rng, m, n, k, split, "w4")
+    bias = torch.from_numpy(rng.standard_normal(n).astype(np.float32)).to(torch.bfloat16).to(dev)
+    runs = [gpu_matmul(dev, qx, qw, bias=bias, split_k="force") for _ in range(3)]
+    assert np.array_equal(runs[0], runs[1]) and np.array_equal(runs[0], runs[2])
+    a, b = to_dev(dev, qx), to_dev(dev, qw)
+    plain = mixedgemm.matmul(a[0], b[0], a[1], b[1], a[2], b[2], a[3], b[3], a[4], b[4], a[5], b[5])
+    assert np.array_equal(runs[0], bits_from_t(plain + bias))
 
 
 @pytest.mark.parametrize("split", [(512, 0, 0), (0, 512, 0), (256, 256, 0)])

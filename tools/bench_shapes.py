@@ -22,6 +22,7 @@ def timed(f, n=50, reps=5):
         e1.record(); torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1) / n * 1000)
     return min(ts)
+ws = torch.empty((64 << 20,), dtype=torch.uint8, device=dev)   # split-K scratch (mm_matmul_workspace_bytes <= 32 MiB)
 print(f"{'layer':13s} {'N':>6s} {'K':>6s} {'M':>5s} {'split':>20s} | {'gemm us':>8s} {'TFLOP/s':>8s} | {'quant us':>8s} | tokens/s (quant+gemm)")
 for name, N, K in SHAPES:
     w = (torch.randn((N, K), generator=g) * 0.02).to(torch.bfloat16).to(dev)
@@ -37,6 +38,6 @@ for name, N, K in SHAPES:
             st = torch.cuda.current_stream().cuda_stream
             ptrs = [pp(t) for t in (a[0], b[0], a[1], b[1], a[2], b[2], a[3], b[3], a[4], b[4], a[5], b[5])]
             # direct C-ABI call (3 us of host time) so that small problems are not measured at the Python shim's ~14 us
-            tg = timed(lambda: lib.mm_matmul(*ptrs, M, N, *split, 1, 0, None, out.data_ptr(), st), n)
+            tg = timed(lambda: lib.mm_matmul_ws(*ptrs, M, N, *split, 1, 0, None, out.data_ptr(), ws.data_ptr(), ws.numel(), st), n)
             tq = timed(lambda: lib.mm_reorder_quantize(x.data_ptr(), M, K, idx.data_ptr(), *split, 0, pp(a[0]), pp(a[1]), pp(a[2]), pp(a[3]), pp(a[4]), pp(a[5]), st), n)
             print(f"{name:13s} {N:6d} {K:6d} {M:5d} {str(split):>20s} | {tg:8.1f} {2*M*N*K/tg/1e6:8.0f} | {tq:8.1f} | {M/(tg+tq)*1e6:,.0f}", flush=True)
