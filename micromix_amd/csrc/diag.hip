@@ -230,6 +230,28 @@ __global__ void __launch_bounds__(256) diag_l2_bw(const uint8_t *buf, unsigned r
     const unsigned mask = region - 1;  // region is a power of two
     const unsigned base = (blockIdx.x * 65536u) & mask;
     float acc = 0.0f;
+    if (mode == 4 || mode == 5) {
+        // register path with a deep queue: every wave keeps 12 x 16 B per lane in flight (mode 5 also stores them to LDS)
+        typedef int v4i_t __attribute__((ext_vector_type(4)));
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)buf, 0, (int)region, 0x00020000);
+        for (int it = 0; it < iters; ++it) {
+            for (int p0 = 0; p0 < kb_per_iter / 4; p0 += 12) {
+                v4i_t q[12];
+#pragma unroll
+                for (int j = 0; j < 12; ++j) {
+                    const unsigned off = (base + (unsigned)(it & 31) * 49152u + (unsigned)((p0 + j) * 4 + wave) * 1024u + lane * 16u) & mask;
+                    q[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0);
+                }
+#pragma unroll
+                for (int j = 0; j < 12; ++j) {
+                    if (mode == 5) *reinterpret_cast<v4i_t *>(smem + ((j * 4 + wave) * 64 + lane) * 16) = q[j];
+                    else acc += __int_as_float(q[j][0] ^ q[j][1] ^ q[j][2] ^ q[j][3]);
+                }
+            }
+        }
+        if (acc == 12345.678f) sink[0] = acc + smem[tid];
+        return;
+    }
     for (int it = 0; it < iters; ++it) {
         for (int p = 0; p < kb_per_iter / 4; ++p) {  // each wave moves 1 KiB per instruction, 4 waves
             unsigned off;
@@ -268,7 +290,7 @@ extern "C" int mm_diag_l2_bw(const void *buf, unsigned region, int stride, int k
             return MM_ERR_LAUNCH;
         attr = true;
     }
-    hipLaunchKernelGGL(mm::diag_l2_bw, dim3(blocks), dim3(256), 131072, (hipStream_t)stream, (const uint8_t *)buf, region, stride,
+    hipLaunchKernelGGL(mm::diag_l2_bw, dim3(blocks), dim3(256), mode >= 4 ? 49152 : 131072, (hipStream_t)stream, (const uint8_t *)buf, region, stride,
                        kb_per_iter, iters, mode, (float *)sink);
     return hipGetLastError() == hipSuccess ? MM_OK : MM_ERR_LAUNCH;
 }

@@ -25,10 +25,17 @@
 #include <math.h>
 #include <stdlib.h>
 #include <type_traits>
+#include <utility>
 
 #include "mx_acc_regs.h"
 #ifndef MM_L2_PREFETCH
 #define MM_L2_PREFETCH 0
+#endif
+#ifndef MM_STAGING
+#define MM_STAGING 0  // 0: LDS-DMA operand pipeline, 1: VGPR-staged (see run_segment_v)
+#endif
+#ifndef MM_NT_STORE
+#define MM_NT_STORE 0
 #endif
 #ifndef MM_DBG
 #define MM_DBG 0  // kernel-developer ablation switches: 1 = no MFMA, 2 = no DMA (results are garbage)

@@ -7,10 +7,10 @@ lib = _lib.load(); dev = torch.device("cuda:0")
 sink = torch.zeros(4, device=dev)
 buf = torch.randint(0, 255, (256 << 20,), dtype=torch.uint8, device=dev)
 st = lambda: torch.cuda.current_stream().cuda_stream
-for region_mb in (2, 16, 64):
+for region_mb in (2, 16):
     region = region_mb << 20
-    for mode, name in ((0, "regs contiguous"), (1, "LDS-DMA contiguous"), (2, "LDS-DMA 8x128B rows stride 4096"), (3, "LDS-DMA rows stride 4224")):
-        for blocks in (64, 128, 256, 512):
+    for mode, name in ((1, "LDS-DMA contiguous"), (2, "LDS-DMA 8x128B rows stride 4096"), (4, "VGPR loads, 12 deep"), (5, "VGPR loads + ds_write")):
+        for blocks in (128, 256, 512, 768):
             m, stride = (2, 4224) if mode == 3 else (mode, 4096)
             kb, iters = 48, 400
             lib.mm_diag_l2_bw(buf.data_ptr(), region, stride, kb, 20, m, blocks, sink.data_ptr(), st())
