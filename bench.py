@@ -149,13 +149,29 @@ def main():
         step()
     barrier()
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    if world == 1:
+        # Kernel duration: the HIP events are attached to the GEMM dispatch itself (hipExtLaunchKernel start/stop events,
+        # mm_diag_set_kernel_events), on the stream the kernel runs on, so they bracket exactly what rocprofv3's kernel
+        # trace reports.  Events recorded around the call would add the ~4 us launch gap to every sample.
+        from micromix_amd import _lib
+        lib = _lib.load()
+        for e0, e1 in evs:      # torch creates the hipEvent_t on first record
+            e0.record()
+            e1.record()
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
     for e0, e1 in evs:
-        e0.record()
-        step()
-        e1.record()
+        if world == 1:
+            lib.mm_diag_set_kernel_events(e0.cuda_event, e1.cuda_event)
+            step()
+        else:
+            e0.record()
+            step()
+            e1.record()
     barrier()
     dt = time.perf_counter() - t0
+    if world == 1:
+        lib.mm_diag_set_kernel_events(None, None)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -160,6 +160,11 @@ int mm_diag_mfma_rate(int shape, int el_a, int el_b, int blocks, int iters, cons
  * there (in-kernel clock = ratio x 100 MHz); NULL disables. */
 int mm_diag_set_clock_buffer(void *buf);
 
+/* Diagnostics: while a pair of hipEvent_t is registered, every tiled-GEMM launch (M > 64) attaches them to its own dispatch
+ * (hipExtLaunchKernel start/stop events), so hipEventElapsedTime gives the kernel's duration as rocprofv3 reports it,
+ * without the launch gap that events recorded around the call include.  NULL, NULL disables.  Used by bench.py. */
+int mm_diag_set_kernel_events(void *start_event, void *stop_event);
+
 /* L2 -> CU read-bandwidth microbenchmark (kernel-developer tool): `blocks` workgroups each move kb_per_iter KiB per
  * iteration from a hot region; mode 0 = register loads, 1 = contiguous LDS-DMA, 2 = LDS-DMA of 8 x 128-byte rows
  * `stride` bytes apart. */

@@ -19,6 +19,7 @@ EXPORTS = (
     "mm_reorder_quantize", "mm_reorder_quantize_gather", "mm_activate_quantize", "mm_downproj_quantize", "mm_matmul",
     "mm_matmul_ws", "mm_matmul_workspace_bytes",
     "mm_diag_mfma", "mm_diag_hw_convert", "mm_diag_mfma_rate", "mm_diag_l2_bw", "mm_diag_set_clock_buffer",
+    "mm_diag_set_kernel_events",
 )
 
 MM_OK, MM_ERR_BAD_SPLIT, MM_ERR_BAD_ARG, MM_ERR_LAUNCH, MM_ERR_UNSUPPORTED, MM_ERR_NO_DEVICE = range(6)
@@ -80,6 +81,8 @@ def load():
     lib.mm_diag_l2_bw.argtypes = [vp, ctypes.c_uint, i, i, i, i, i, vp, vp]
     lib.mm_diag_set_clock_buffer.restype = i
     lib.mm_diag_set_clock_buffer.argtypes = [vp]
+    lib.mm_diag_set_kernel_events.restype = i
+    lib.mm_diag_set_kernel_events.argtypes = [vp, vp]
     _lib = lib
     return lib
 

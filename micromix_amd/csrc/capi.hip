@@ -8,6 +8,7 @@
 
 
 static thread_local char g_last_error[256] = "";
+static hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;  // diagnostics: see mm_diag_set_kernel_events
 static unsigned long long *g_clock_buf = nullptr;  // diagnostics: see mm_diag_set_clock_buffer
 
 static int fail_hip(hipError_t e, const char *where) {
@@ -135,6 +136,8 @@ int mm_matmul_ws(const uint8_t *AN, const uint8_t *BN, const uint8_t *AS, const 
     a.bias = (const uint16_t *)bias_bf16;
     a.D = (uint16_t *)D_bf16;
     a.clock_out = g_clock_buf;
+    a.ev_start = g_ev_start;
+    a.ev_stop = g_ev_stop;
     a.ws = (float *)workspace;
     a.ws_bytes = workspace ? workspace_bytes : 0;
     a.splits = 0;
@@ -142,6 +145,12 @@ int mm_matmul_ws(const uint8_t *AN, const uint8_t *BN, const uint8_t *AS, const 
     a.split_first[0] = a.split_first[1] = a.split_first[2] = a.split_first[3] = 0;
     hipError_t e = mm::launch_mx_gemm(a, wmode == MM_W_FP4, (hipStream_t)stream);
     return e == hipSuccess ? MM_OK : fail_hip(e, "mm_matmul");
+}
+
+int mm_diag_set_kernel_events(void *start_event, void *stop_event) {
+    g_ev_start = (hipEvent_t)start_event;
+    g_ev_stop = (hipEvent_t)stop_event;
+    return MM_OK;
 }
 
 int mm_diag_set_clock_buffer(void *buf) {

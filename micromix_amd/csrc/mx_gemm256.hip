@@ -22,6 +22,7 @@
 //    fragments are already in registers.
 //  * with tokens on MFMA rows the accumulator has the feature index on the lane, so the epilogue transposes
 //    each wave's tile through LDS (free at that point) and stores whole 256-byte rows.
+#include <hip/hip_ext.h>
 #include <math.h>
 #include <stdlib.h>
 #include <type_traits>
@@ -179,7 +180,10 @@ static hipError_t launch_tile(KernelT kern, bool &attr_done, int lds_bytes, int 
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL(kern, dim3(tiles), dim3(threads), lds_bytes, stream, a);
+    if (a.ev_start != nullptr && a.ev_stop != nullptr)
+        hipExtLaunchKernelGGL(kern, dim3(tiles), dim3(threads), lds_bytes, stream, a.ev_start, a.ev_stop, 0, a);
+    else
+        hipLaunchKernelGGL(kern, dim3(tiles), dim3(threads), lds_bytes, stream, a);
     return hipGetLastError();
 }
 

@@ -22,6 +22,7 @@ struct GemmArgs {
     int force_split;        // MM_SPLIT_K_ALWAYS
     int splits;             // filled in by the launcher when it splits K
     int split_first[4];     // splits [split_first[i], split_first[i+1]) work on segment i
+    hipEvent_t ev_start, ev_stop;   // diagnostics only (mm_diag_set_kernel_events): recorded at the GEMM dispatch itself
     unsigned long long *clock_out;  // diagnostics only (mm_diag_set_clock_buffer): per workgroup {shader cycles, 100 MHz ticks}
 };
 

@@ -12,9 +12,17 @@ for f in glob.glob(out + "/trace/*/*_kernel_stats.csv"):
     lines.append("== rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 200 --warmup 50 ==")
     for r in rows:
         lines.append(f"{r['Name'][:70]:70s} calls {r['Calls']:>5s} avg {float(r['AverageNs'])/1e3:8.2f} us min {float(r['MinNs'])/1e3:8.2f} max {float(r['MaxNs'])/1e3:8.2f} {float(r['Percentage']):6.2f}%")
+# the bench's timed region inside the same trace: launches warmup+1 .. warmup+steps of the w4 GEMM kernel (W = 50, K = 200)
+for f in glob.glob(out + "/trace/*/*_kernel_trace.csv"):
+    d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in csv.DictReader(open(f))
+         if "mx_gemm256_kernel<true, false>" in r["Kernel_Name"]]
+    if len(d) >= 250:
+        t = d[50:250]
+        lines.append(f"timed region of bench.py (GEMM launches 51..250 of the trace): avg {sum(t)/len(t):.2f} us min {min(t):.2f} max {max(t):.2f}"
+                     "   <- compare with roofline.kernel_us")
 bench_line = [l for l in open(out + "/bench_under_rocprof.log") if l.startswith("{")]
 if bench_line:
-    lines.append("== bench.py JSON line of the same (profiled) run ==")
+    lines.append("== bench.py JSON line of the same (profiled) run; its event-based kernel_us reads ~4 us high under the profiler ==")
     lines.append(bench_line[-1].strip())
 agg = collections.defaultdict(list)
 for f in glob.glob(out + "/pmc_*/*/*_counter_collection.csv"):
@@ -40,5 +48,11 @@ if g("FETCH_SIZE") is not None and g("WRITE_SIZE") is not None:
     q = lambda c: stat.get(("quant", c))
     if q("FETCH_SIZE") is not None and q("WRITE_SIZE") is not None:
         lines.append(f"quantize_x HBM bytes per launch: {int(2*q('FETCH_SIZE')*1024 + q('WRITE_SIZE')*1024)} (algorithmic 50864128)")
+plain = os.path.join(root, "gpurun_out", "bench_plain.log")
+if os.path.exists(plain):
+    bl = [l for l in open(plain) if l.startswith("{")]
+    if bl:
+        lines.append("== bench.py JSON line of an unprofiled run on the same box ==")
+        lines.append(bl[-1].strip())
 open(os.path.join(prof, f"{tag}_summary.txt"), "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
