@@ -14,6 +14,8 @@
  *                           (bindings: mgemm/src/bindings.cpp:104-151,155-202,206-253)
  *   mm_matmul            <- matmul_host / matmul_w4_host   mgemm/src/gemm.cu:26-78
  *                           (binding: mgemm/src/bindings.cpp:50-102)
+ *   mm_rmsnorm_quantize  <- run_rmsnorm_bf16_mixed   mgemm/src/rmsnorm.cu:314-352 (binding bindings.cpp:257-303)
+ *   mm_activate_quantize / mm_downproj_quantize <- mgemm/src/activate.cu:510-551 (bindings.cpp:307-387)
  *   mm_sf_bytes_x / _w   <- SF allocation sizes      mgemm/src/bindings.cpp:120-123,170-172
  *   mm_sf_offset         <- SF layout atom            mgemm/include/sm120_sf_layout.h:170-173
  *
@@ -109,6 +111,21 @@ int mm_activate_quantize(const void *A_bf16, const void *B_bf16, int rows, int K
                          uint8_t *oO, uint8_t *sfN, uint8_t *sfS, uint8_t *sfO, mm_stream_t stream);
 int mm_downproj_quantize(const void *W_bf16, int rows, int KN, int KS, int KO, int mode, uint8_t *oN, uint8_t *oS, uint8_t *oO,
                          uint8_t *sfN, uint8_t *sfS, uint8_t *sfO, mm_stream_t stream);
+
+/*
+ * RMSNorm fused with reorder + quantize (reference: rmsnorm_bf16_mixed_kernel, mgemm/src/rmsnorm.cu:95-312; binding
+ * rmsnorm_quantize_x, bindings.cpp:257-303).  v = bf16(x[idx] * w[idx] * rsqrt(mean(x^2) + eps)), then the mixed quantizer of
+ * mm_reorder_quantize on v (zero block -> byte 126) -- with the reference's extra step (rmsnorm.cu:262-267): the scaled value
+ * is rounded to an integer (half away from zero), clamped and rounded through bf16 before the element conversion.
+ *   flags  MM_RMS_REFERENCE (0): as the reference;  MM_RMS_NO_INTEGER_ROUND: without that step
+ *   X_bf16 [rows, K], W_bf16 [K] norm weight, reorder_index [K] int16; outputs as mm_reorder_quantize(MM_QUANT_MIXED),
+ *   SF buffers mm_sf_bytes_x(rows, Kseg).  Any K % 128 == 0 up to 32768 (the reference compiles 3072, 3584, 4096, 5120 and its
+ *   block reduction is only right for 4096).
+ */
+enum mm_rmsnorm_flags { MM_RMS_REFERENCE = 0, MM_RMS_NO_INTEGER_ROUND = 1 };
+int mm_rmsnorm_quantize(const void *X_bf16, const void *W_bf16, float eps, int rows, int K, const int16_t *reorder_index, int KN,
+                        int KS, int KO, int flags, uint8_t *oN, uint8_t *oS, uint8_t *oO, uint8_t *sfN, uint8_t *sfS,
+                        uint8_t *sfO, mm_stream_t stream);
 
 /*
  * Three-segment mixed-precision block-scaled GEMM:

@@ -17,7 +17,7 @@ EXPORTS = (
     "mm_version", "mm_strerror", "mm_last_error",
     "mm_sf_bytes_x", "mm_sf_bytes_w", "mm_sf_offset",
     "mm_reorder_quantize", "mm_reorder_quantize_gather", "mm_activate_quantize", "mm_downproj_quantize", "mm_matmul",
-    "mm_matmul_ws", "mm_matmul_workspace_bytes",
+    "mm_matmul_ws", "mm_matmul_workspace_bytes", "mm_rmsnorm_quantize",
     "mm_diag_mfma", "mm_diag_hw_convert", "mm_diag_mfma_rate", "mm_diag_l2_bw", "mm_diag_set_clock_buffer",
     "mm_diag_set_kernel_events",
 )
@@ -26,6 +26,7 @@ MM_OK, MM_ERR_BAD_SPLIT, MM_ERR_BAD_ARG, MM_ERR_LAUNCH, MM_ERR_UNSUPPORTED, MM_E
 MM_QUANT_MIXED, MM_QUANT_W4 = 0, 1
 MM_W_MATCH, MM_W_FP4 = 0, 1
 MM_ROUND_PER_SEGMENT, MM_ROUND_ONCE, MM_SPLIT_K_ALWAYS = 0, 1, 2
+MM_RMS_REFERENCE, MM_RMS_NO_INTEGER_ROUND = 0, 1
 
 _lib = None
 
@@ -67,6 +68,8 @@ def load():
     lib.mm_downproj_quantize.argtypes = [vp, i, i, i, i, i, vp, vp, vp, vp, vp, vp, vp]
     lib.mm_matmul.restype = i
     lib.mm_matmul.argtypes = [vp] * 12 + [i] * 7 + [vp, vp, vp]
+    lib.mm_rmsnorm_quantize.restype = i
+    lib.mm_rmsnorm_quantize.argtypes = [vp, vp, ctypes.c_float, i, i, vp, i, i, i, i] + [vp] * 7
     lib.mm_matmul_ws.restype = i
     lib.mm_matmul_ws.argtypes = [vp] * 12 + [i] * 7 + [vp, vp, vp, ctypes.c_size_t, vp]
     lib.mm_matmul_workspace_bytes.restype = ctypes.c_size_t

@@ -92,6 +92,19 @@ int mm_downproj_quantize(const void *W_bf16, int rows, int KN, int KS, int KO, i
     return e == hipSuccess ? MM_OK : fail_hip(e, "mm_downproj_quantize");
 }
 
+int mm_rmsnorm_quantize(const void *X_bf16, const void *W_bf16, float eps, int rows, int K, const int16_t *reorder_index, int KN,
+                        int KS, int KO, int flags, uint8_t *oN, uint8_t *oS, uint8_t *oO, uint8_t *sfN, uint8_t *sfS,
+                        uint8_t *sfO, mm_stream_t stream) {
+    if (!split_ok(K, KN, KS, KO)) return MM_ERR_BAD_SPLIT;
+    if (rows < 0 || K > 32768) return MM_ERR_BAD_ARG;
+    if (rows == 0) return MM_OK;
+    if (!X_bf16 || !W_bf16 || !reorder_index) return MM_ERR_BAD_ARG;
+    if ((KN && (!oN || !sfN)) || (KS && (!oS || !sfS)) || (KO && (!oO || !sfO))) return MM_ERR_BAD_ARG;
+    hipError_t e = mm::launch_rmsnorm_quantize(X_bf16, W_bf16, eps, rows, K, reorder_index, KN, KS, KO,
+                                               !(flags & MM_RMS_NO_INTEGER_ROUND), oN, oS, oO, sfN, sfS, sfO, (hipStream_t)stream);
+    return e == hipSuccess ? MM_OK : fail_hip(e, "mm_rmsnorm_quantize");
+}
+
 size_t mm_matmul_workspace_bytes(int M, int N, int KN, int KS, int KO, int wmode, int flags) {
     (void)wmode;
     if (M <= 0 || N <= 0 || KN < 0 || KS < 0 || KO < 0 || (KN % 128) || (KS % 128) || (KO % 128)) return 0;

@@ -19,66 +19,10 @@
 #ifndef MM_QDBG
 #define MM_QDBG 0  // kernel-developer A/B switches: 1 = tiny-block path out of line, 2 = byte SF stores, 4 = fixed 2048-block grid
 #endif
+#include "mx_group_convert.h"
 #include "mx_kernels.h"
 
 namespace mm {
-
-typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf32 __attribute__((ext_vector_type(32)));
-typedef short s2 __attribute__((ext_vector_type(2)));
-typedef unsigned u6 __attribute__((ext_vector_type(6)));
-
-// e == -127 (every element of the block is below FMAX * 2^-127): 2^127 times the value, integer encoder.
-// Inlined on purpose: as a __noinline__ call it cost 40 % of the kernel's time (15.3 vs 10.9 us at 4096 x 4096) although
-// it is practically never taken -- the call site pins the caller's registers.
-#if (MM_QDBG & 1)
-#define MM_TINY_INLINE __noinline__
-#else
-#define MM_TINY_INLINE __forceinline__
-#endif
-template <int EL>
-__device__ MM_TINY_INLINE void quantize_group_tiny(const uint32_t *__restrict__ v, uint8_t *__restrict__ out) {
-    const float rs = __uint_as_float(254u << 23);  // 2^127
-    uint32_t c[32];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        c[2 * i] = encode<EL>(bf16_bits_to_f32(v[i] & 0xFFFFu) * rs);
-        c[2 * i + 1] = encode<EL>(bf16_bits_to_f32(v[i] >> 16) * rs);
-    }
-    if constexpr (EL == EL_FP8) {
-        uint32_t w[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) w[i] = c[4 * i] | (c[4 * i + 1] << 8) | (c[4 * i + 2] << 16) | (c[4 * i + 3] << 24);
-        uint4 *o = reinterpret_cast<uint4 *>(out);
-        o[0] = make_uint4(w[0], w[1], w[2], w[3]);
-        o[1] = make_uint4(w[4], w[5], w[6], w[7]);
-    } else if constexpr (EL == EL_FP4) {
-        uint32_t w[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            uint32_t x = 0;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) x |= (c[8 * i + k] & 0xFu) << (4 * k);  // element 2i in the low nibble
-            w[i] = x;
-        }
-        *reinterpret_cast<uint4 *>(out) = make_uint4(w[0], w[1], w[2], w[3]);
-    } else {
-        // dense little-endian 6-bit stream: 32 codes -> 192 bits -> three 64-bit words
-        unsigned long long w[3] = {0ull, 0ull, 0ull};
-#pragma unroll
-        for (int i = 0; i < 32; ++i) {
-            const int bit = 6 * i, word = bit >> 6, off = bit & 63;
-            const unsigned long long code = c[i] & 0x3Fu;
-            w[word] |= code << off;
-            if (off > 58) w[word + 1] |= code >> (64 - off);
-        }
-        unsigned long long *o = reinterpret_cast<unsigned long long *>(out);
-        o[0] = w[0];
-        o[1] = w[1];
-        o[2] = w[2];
-    }
-}
 
 // One 32-element group: gather (two bf16 per VGPR), block absmax, UE8M0 scale, convert, pack, store; returns the
 // scale byte.  `ix` holds BYTE offsets into the staged row (index << 1), two per register.
@@ -106,48 +50,7 @@ __device__ __forceinline__ uint32_t quantize_group(const uint8_t *__restrict__ r
         quantize_group_tiny<EL>(v, out);
         return 0u;
     }
-    const float scale = __uint_as_float((uint32_t)(127 + e) << 23);  // 2^e, a normal fp32
-    if constexpr (EL == EL_FP8) {
-        uint32_t w[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            bf2 a, b;
-            __builtin_memcpy(&a, &v[2 * i], 4);
-            __builtin_memcpy(&b, &v[2 * i + 1], 4);
-            s2 r = {0, 0};
-            r = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(r, a, scale, false);
-            r = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(r, b, scale, true);
-            __builtin_memcpy(&w[i], &r, 4);
-        }
-        uint4 *o = reinterpret_cast<uint4 *>(out);
-        o[0] = make_uint4(w[0], w[1], w[2], w[3]);
-        o[1] = make_uint4(w[4], w[5], w[6], w[7]);
-    } else if constexpr (EL == EL_FP4) {
-        uint32_t w[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            uint32_t r = 0;
-            bf2 a;
-            __builtin_memcpy(&a, &v[4 * i], 4);
-            r = __builtin_amdgcn_cvt_scalef32_pk_fp4_bf16(r, a, scale, 0);
-            __builtin_memcpy(&a, &v[4 * i + 1], 4);
-            r = __builtin_amdgcn_cvt_scalef32_pk_fp4_bf16(r, a, scale, 1);
-            __builtin_memcpy(&a, &v[4 * i + 2], 4);
-            r = __builtin_amdgcn_cvt_scalef32_pk_fp4_bf16(r, a, scale, 2);
-            __builtin_memcpy(&a, &v[4 * i + 3], 4);
-            r = __builtin_amdgcn_cvt_scalef32_pk_fp4_bf16(r, a, scale, 3);
-            w[i] = r;
-        }
-        *reinterpret_cast<uint4 *>(out) = make_uint4(w[0], w[1], w[2], w[3]);
-    } else {
-        bf32 x;
-        __builtin_memcpy(&x, v, 64);
-        const u6 r = __builtin_amdgcn_cvt_scalef32_pk32_bf6_bf16(x, scale);
-        uint2 *o = reinterpret_cast<uint2 *>(out);
-        o[0] = make_uint2(r[0], r[1]);
-        o[1] = make_uint2(r[2], r[3]);
-        o[2] = make_uint2(r[4], r[5]);
-    }
+    convert_group<EL>(v, __uint_as_float((uint32_t)(127 + e) << 23), out);  // scale 2^e, a normal fp32
     return (uint32_t)(e + 127);
 }
 

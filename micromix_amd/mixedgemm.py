@@ -17,8 +17,9 @@ Differences from the reference, all deliberate:
   * `matmul` takes optional keyword-only `bias` and `rounding` arguments (extensions).
     activate_quantize_x(A, B, KN, KS, KO)             -> (XN, XS, XO, SFXN, SFXS, SFXO)   (section 8f rank 1)
     downproj_quantize_w / _w4 (W, KN, KS, KO)         -> (WN, WS, WO, SFWN, SFWS, SFWO)
-The remaining exports of the reference module (rmsnorm_quantize_x, FlashInfer KV ops) are outside
-the hot path; they raise NotImplementedError.
+    rmsnorm_quantize_x(X, W, eps, reorder_index, KN, KS, KO) -> (XN, XS, XO, SFXN, SFXS, SFXO)    (section 8f rank 2)
+The remaining exports of the reference module (FlashInfer KV ops) are outside the hot path; they raise
+NotImplementedError.
 """
 from __future__ import annotations
 
@@ -27,7 +28,7 @@ import torch
 from . import _lib
 
 __all__ = ["matmul", "reorder_quantize_x", "reorder_quantize_w", "reorder_quantize_w4", "activate_quantize_x",
-           "downproj_quantize_w", "downproj_quantize_w4"]
+           "downproj_quantize_w", "downproj_quantize_w4", "rmsnorm_quantize_x"]
 
 
 def _stream_ptr(device) -> int:
@@ -272,6 +273,43 @@ def _not_on_path(name):
     return f
 
 
-rmsnorm_quantize_x = _not_on_path("rmsnorm_quantize_x")
+def rmsnorm_quantize_x(X, W, eps, reorder_index, KN, KS, KO, *, integer_round=True):
+    """bindings.cpp:257-303 / rmsnorm.cu:95-312.  RMSNorm(X; W, eps) -> reorder -> mixed quantize, one kernel.
+
+    X [M,K] bf16, W [K] bf16 norm weight -> (XN [M,KN/2], XS [M,3KS/4], XO [M,KO], SFXN, SFXS, SFXO), the tuple
+    `QLinearLayer.forward` accepts in place of a tensor, so q/k/v (or gate/up) share one quantization.
+    `integer_round=True` (default) reproduces the reference, which rounds the scaled value to an integer before the element
+    conversion (rmsnorm.cu:262-267); `False` drops that step.
+    """
+    lib = _lib.load()
+    if not (isinstance(X, torch.Tensor) and X.is_cuda and isinstance(W, torch.Tensor) and isinstance(reorder_index, torch.Tensor)
+            and _ok(X, torch.bfloat16, X.get_device()) and _ok(W, torch.bfloat16, X.get_device())
+            and _ok(reorder_index, torch.int16, X.get_device())):
+        _check_tensor(X, "X", torch.bfloat16)
+        _check_tensor(W, "W", torch.bfloat16, X.device)
+        _check_tensor(reorder_index, "reorder_index", torch.int16, X.device)
+    if X.dim() != 2:
+        raise RuntimeError("X must be 2-D [rows, K]")
+    KN, KS, KO = int(KN), int(KS), int(KO)
+    rows, K = X.shape
+    if (KN < 0 or KS < 0 or KO < 0 or KN % 128 or KS % 128 or KO % 128 or KN + KS + KO != K or reorder_index.numel() != K
+            or W.numel() != K):
+        _lib.check(_lib.MM_ERR_BAD_SPLIT, "rmsnorm_bf16_mixed")    # bindings.cpp:298 "Value error in run_rmsnorm_bf16_mixed"
+    dev, u8 = X.device, torch.uint8
+    oN = torch.empty((rows, KN // 2), dtype=u8, device=dev)
+    oS = torch.empty((rows, KS // 4 * 3), dtype=u8, device=dev)
+    oO = torch.empty((rows, KO), dtype=u8, device=dev)
+    sfN = torch.empty((_sf_bytes_x(rows, KN),), dtype=u8, device=dev)
+    sfS = torch.empty((_sf_bytes_x(rows, KS),), dtype=u8, device=dev)
+    sfO = torch.empty((_sf_bytes_x(rows, KO),), dtype=u8, device=dev)
+    with _on_device(dev.index):
+        st = lib.mm_rmsnorm_quantize(_ptr(X), _ptr(W), float(eps), rows, K, _ptr(reorder_index), KN, KS, KO,
+                                     _lib.MM_RMS_REFERENCE if integer_round else _lib.MM_RMS_NO_INTEGER_ROUND,
+                                     _ptr(oN), _ptr(oS), _ptr(oO), _ptr(sfN), _ptr(sfS), _ptr(sfO), _stream_ptr(dev))
+    if st:
+        _lib.check(st, "rmsnorm_bf16_mixed")
+    return oN, oS, oO, sfN, sfS, sfO
+
+
 for _n in ("batch_decode_i4", "batch_decode_f16", "init_kv_i4", "init_kv_f16", "append_kv_i4", "append_kv_f16"):
     globals()[_n] = _not_on_path(_n)

@@ -293,6 +293,88 @@ def reorder_quantize(x_bits: np.ndarray, idx: np.ndarray, kn: int, ks: int, ko: 
 
 
 # --------------------------------------------------------------------------
+# RMSNorm fused with reorder + quantize (rmsnorm.cu:95-312; bindings.cpp:257-303) -- SURVEY.md section 8f rank 2
+# --------------------------------------------------------------------------
+def rmsnorm_rvar(x_bits: np.ndarray, eps: float) -> np.ndarray:
+    """Reciprocal RMS of every row, fp32, in the reference's summation order (rmsnorm.cu:143-185).
+
+    One partial sum per 32-group thread t of T = K/32: the squares of elements i*K/4 + 8t + j (i = 0..3, j = 0..7)
+    added one after the other in fp32 (:147-156, local_sum_p2 :43-50); then the block tree s[t] += s[t + stride] for
+    stride = P/2 .. 1 (:159-175).  The reference hard-codes the tree for T = 128 (K = 4096): with T = 160 (K = 5120)
+    it drops the last 32 partial sums and with T = 96 it reads past its shared array.  Here the tree is the same one
+    over P = next power of two >= T with zero padding, which equals the reference's for K = 4096 and is the evident
+    intent for the other K.  rvar = 1 / sqrt(sum / K + eps) with correctly rounded fp32 divide and square root; the
+    reference's rsqrt() is a 2-ulp hardware approximation whose bits cannot be pinned without a Blackwell GPU.
+    """
+    x = bf16_to_f32(np.asarray(x_bits))
+    rows, k = x.shape
+    t = k // GROUP
+    sq = (x * x).astype(np.float32)                      # bf16 x bf16 is exact in fp32
+    part = np.zeros((rows, t), np.float32)
+    for i in range(4):
+        blk = sq[:, i * (k // 4):(i + 1) * (k // 4)].reshape(rows, t, 8)
+        for j in range(8):
+            part = (part + blk[:, :, j]).astype(np.float32)
+    p = 1
+    while p < t:
+        p *= 2
+    s = np.zeros((rows, p), np.float32)
+    s[:, :t] = part
+    stride = p // 2
+    while stride >= 1:
+        s[:, :stride] = (s[:, :stride] + s[:, stride:2 * stride]).astype(np.float32)
+        stride //= 2
+    mean = (s[:, 0] / np.float32(k)).astype(np.float32)
+    return (np.float32(1.0) / np.sqrt((mean + np.float32(eps)).astype(np.float32))).astype(np.float32)
+
+
+def _round_half_away(x: np.ndarray) -> np.ndarray:
+    return (np.sign(x) * np.floor(np.abs(x) + 0.5)).astype(np.float32)
+
+
+def rmsnorm_quantize(x_bits: np.ndarray, w_bits: np.ndarray, eps: float, idx: np.ndarray, kn: int, ks: int, ko: int,
+                     integer_round: bool = True, sf_fill: int = 0):
+    """Restates rmsnorm_bf16_mixed_kernel (rmsnorm.cu:95-312).
+
+    v[i] = bf16((float(x[idx[i]]) * float(w[idx[i]])) * rvar)   (:190-195); per 32-group amax, scale = amax == 0 ? 0.5 :
+    2^ceil(log2(amax / FMAX)) (:216-245, as reorder.cu); then -- and this is what the reference does, rmsnorm.cu:262-267 --
+    q = convert(bf16(clamp(round(v / scale), -FMAX, FMAX))): the value is rounded to an INTEGER (half away from zero)
+    before the element conversion.  ``integer_round=False`` gives the quantizer without that step (identical to
+    reorder_quantize applied to the normalised row).
+    """
+    x_bits = np.asarray(x_bits)
+    rows, k = x_bits.shape
+    check_split(k, kn, ks, ko)
+    idx = np.asarray(idx).astype(np.int64)
+    rvar = rmsnorm_rvar(x_bits, eps)
+    xv = bf16_to_f32(x_bits)[:, idx]
+    wv = bf16_to_f32(np.asarray(w_bits))[idx]
+    prod = (xv * wv[None, :]).astype(np.float32)         # exact
+    v = bf16_to_f32(f32_to_bf16((prod * rvar[:, None]).astype(np.float32)))
+    outs, sfs = [], []
+    col = 0
+    for kseg, fmt in zip((kn, ks, ko), ("fp4", "fp6", "fp8")):
+        seg = v[:, col:col + kseg]
+        col += kseg
+        g = seg.reshape(rows, kseg // GROUP, GROUP)
+        amax = np.abs(g).max(axis=-1) if kseg else np.zeros((rows, 0), np.float32)
+        e = scale_exponent(amax, fmt)
+        q = (g.astype(np.float64) * np.exp2(-e.astype(np.float64))[..., None]).astype(np.float32)
+        if integer_round:
+            fmax = np.float32(FORMATS[fmt]["fmax"])
+            q = bf16_to_f32(f32_to_bf16(np.clip(_round_half_away(q), -fmax, fmax)))
+        packed = _PACK[fmt](encode(q.reshape(rows, kseg), fmt))
+        sf = np.full((sf_size_x(rows, kseg),), sf_fill, dtype=np.uint8)
+        if kseg:
+            r = np.arange(rows)[:, None]
+            j = np.arange(kseg // 32)[None, :]
+            sf[sf_offset(r, j, kseg)] = (e + 127).astype(np.uint8)
+        outs.append(np.ascontiguousarray(packed).reshape(rows, packed_width(fmt, kseg)))
+        sfs.append(sf)
+    return (*outs, *sfs)
+
+
+# --------------------------------------------------------------------------
 # reorder-free quantizers (activate.cu:44-202 silu(a)*b; :208-500 weights) -- SURVEY.md section 8f rank 1
 # --------------------------------------------------------------------------
 def scale_exponent_f32(amax: np.ndarray, fmt: str) -> np.ndarray:

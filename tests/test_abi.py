@@ -69,7 +69,7 @@ def test_python_surface_matches_reference_signatures():
     assert list(inspect.signature(mixedgemm.activate_quantize_x).parameters) == ["A", "B", "KN", "KS", "KO"]
     assert list(inspect.signature(mixedgemm.downproj_quantize_w).parameters) == ["W", "KN", "KS", "KO"]
     assert list(inspect.signature(mixedgemm.downproj_quantize_w4).parameters) == ["W", "KN", "KS", "KO"]
-    for name in ("rmsnorm_quantize_x", "batch_decode_i4", "init_kv_f16", "append_kv_i4"):
+    for name in ("batch_decode_i4", "batch_decode_f16", "init_kv_f16", "append_kv_i4"):
         with pytest.raises(NotImplementedError):
             getattr(mixedgemm, name)()
 

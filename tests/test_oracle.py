@@ -234,3 +234,26 @@ def test_direct_quantizers():
     assert abs(v[0, 1] - 0.7310586) < 1e-6 and abs(v[0, 2] + 0.26894143) < 1e-6 and v[0, 0] == 0
     e = o.scale_exponent_f32(np.array([6.0, 6.0000005, 1e-7, 448.0, 3.0], np.float32), "fp4")
     assert e.tolist() == [0, 1, 0, 7, -1]
+
+
+def test_rmsnorm_quantize_oracle_properties():
+    """rmsnorm.cu:95-312 restatement: rvar close to the fp64 value; integer_round=False equals reorder_quantize of the
+    normalised row; integer_round=True only ever produces integer-valued elements."""
+    rng = np.random.default_rng(21)
+    rows, k, split = 6, 1024, (512, 256, 256)
+    xb = o.f32_to_bf16((rng.standard_normal((rows, k)) * 2).astype(np.float32))
+    wb = o.f32_to_bf16((1 + 0.1 * rng.standard_normal(k)).astype(np.float32))
+    idx = rng.permutation(k)
+    rvar = o.rmsnorm_rvar(xb, 1e-5)
+    truth = 1.0 / np.sqrt((o.bf16_to_f32(xb).astype(np.float64) ** 2).mean(1) + 1e-5)
+    assert np.all(np.abs(rvar - truth) <= 4e-7 * truth)
+    normed = o.f32_to_bf16(((o.bf16_to_f32(xb) * o.bf16_to_f32(wb)[None, :]).astype(np.float32) * rvar[:, None]).astype(np.float32))
+    a = o.rmsnorm_quantize(xb, wb, 1e-5, idx, *split, integer_round=False)
+    b = o.reorder_quantize(normed, idx, *split, "x")
+    assert all(np.array_equal(p, q) for p, q in zip(a, b))
+    c = o.rmsnorm_quantize(xb, wb, 1e-5, idx, *split)
+    vals = o.decode(c[2], "fp8")                     # fp8 segment: element values before the block scale
+    assert np.array_equal(vals, np.round(vals))
+    vals4 = o.decode(o.unpack_fp4(c[0]), "fp4")
+    assert np.array_equal(vals4, np.round(vals4))
+    assert all(np.array_equal(p, q) for p, q in zip(a[3:], c[3:]))    # the scales do not depend on the rounding step
