@@ -329,7 +329,9 @@ def rmsnorm_rvar(x_bits: np.ndarray, eps: float) -> np.ndarray:
 
 
 def _round_half_away(x: np.ndarray) -> np.ndarray:
-    return (np.sign(x) * np.floor(np.abs(x) + 0.5)).astype(np.float32)
+    """C roundf(): nearest integer, halves away from zero, the sign of a zero result kept (round(-0.3) = -0.0)."""
+    x = np.asarray(x, np.float32)
+    return np.copysign(np.floor(np.abs(x) + np.float32(0.5)), x).astype(np.float32)
 
 
 def rmsnorm_quantize(x_bits: np.ndarray, w_bits: np.ndarray, eps: float, idx: np.ndarray, kn: int, ks: int, ko: int,
