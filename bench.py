@@ -112,11 +112,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # MICROMIX_BENCH_BACKEND=gloo is a dry run of the multi-rank code path on a box with fewer GPUs than ranks (ranks share
+    # devices, the all-reduce is staged through the host): for testing the script, not a measurement
+    backend = os.environ.get("MICROMIX_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     x_cpu, w_cpu, idx_cpu = synth_inputs()
     x, w, idx = x_cpu.to(dev), w_cpu.to(dev), idx_cpu.to(dev)
@@ -148,35 +155,41 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
+    # timed region: exactly K steps, nothing else in the loop
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    # Kernel duration for the roofline: a second pass of the same K steps with HIP events attached to the GEMM dispatch
+    # itself (hipExtLaunchKernel start/stop events, mm_diag_set_kernel_events) on the stream the kernel runs on; they
+    # bracket exactly what rocprofv3's kernel trace reports.  It is a separate pass because attaching events widens the gap
+    # between consecutive launches by ~4 us (it would cost `value` 5-7 %), and events recorded AROUND the call would
+    # include that gap in every sample.
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     if world == 1:
-        # Kernel duration: the HIP events are attached to the GEMM dispatch itself (hipExtLaunchKernel start/stop events,
-        # mm_diag_set_kernel_events), on the stream the kernel runs on, so they bracket exactly what rocprofv3's kernel
-        # trace reports.  Events recorded around the call would add the ~4 us launch gap to every sample.
         from micromix_amd import _lib
         lib = _lib.load()
         for e0, e1 in evs:      # torch creates the hipEvent_t on first record
             e0.record()
             e1.record()
         torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for e0, e1 in evs:
-        if world == 1:
+        for e0, e1 in evs:
             lib.mm_diag_set_kernel_events(e0.cuda_event, e1.cuda_event)
             step()
-        else:
+        lib.mm_diag_set_kernel_events(None, None)
+    else:
+        for e0, e1 in evs:      # per-step device time of GEMM + all-reduce on this rank's stream
             e0.record()
             step()
             e1.record()
     barrier()
-    dt = time.perf_counter() - t0
-    if world == 1:
-        lib.mm_diag_set_kernel_events(None, None)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    kern_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in evs]))   # per-step device time on this rank's stream
+    kern_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in evs]))
     ms_per_step = dt * 1e3 / args.steps
     flop = 2.0 * M * N * K
     value = flop / (ms_per_step * 1e-3) / 1e12
@@ -200,7 +213,8 @@ def main():
             "frac": round(achieved / PEAK_TFLOPS_FP8, 4),
             "traffic": traffic.get("hbm_bytes_per_launch") if traffic else None,
             "kernel": "mm::g256::mx_gemm256_kernel<true,false> (fused three-segment scaled-MFMA GEMM, 256x256 tiles)",
-            "kernel_us": round(kern_ms * 1e3, 2), "algorithmic_flop_per_launch": flop,
+            "kernel_us": round(kern_ms * 1e3, 2), "kernel_us_source": "HIP events attached to each GEMM dispatch, second pass of K steps",
+            "algorithmic_flop_per_launch": flop,
             "algorithmic_bytes_per_launch": M * K + N * K // 2 + (M + N) * K // 32 + 2 * M * N,
             "note": "peak = dense fp8-operand scaled-MFMA rate; A is fp8 so the fp8 rate applies to the whole launch",
         }
@@ -243,6 +257,22 @@ def main():
         }
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(x_cpu, w_cpu, idx_cpu)
+    if world > 1:
+        # the same GEMM with rows instead of K split across the GPUs (every rank multiplies its own 4096 token rows by the
+        # replicated weights, no exchange): what the node delivers when the linear layer is used data-parallel
+        b = mixedgemm.reorder_quantize_w4(w, idx, *SPLIT)
+        a = mixedgemm.reorder_quantize_x(x, idx, *SPLIT)
+        for _ in range(args.warmup):
+            mixedgemm.matmul(a[0], b[0], a[1], b[1], a[2], b[2], a[3], b[3], a[4], b[4], a[5], b[5], out=out)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            mixedgemm.matmul(a[0], b[0], a[1], b[1], a[2], b[2], a[3], b[3], a[4], b[4], a[5], b[5], out=out)
+        barrier()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        extra["row_parallel_no_exchange"] = {"value": round(world * flop / (float(t.item()) / args.steps) / 1e12, 2), "unit": "TFLOP/s",
+                                             "scaling": "weak", "global_rows": world * M}
     if rank == 0:
         result.update(extra)
         print(json.dumps(result), flush=True)
