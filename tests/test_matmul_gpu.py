@@ -42,6 +42,7 @@ SHAPES = [
     (1, 128, 512, (256, 128, 128)), (7, 256, 384, (128, 128, 128)), (33, 384, 1024, (512, 128, 384)),
     (130, 256, 4096, (2048, 1024, 1024)), (257, 512, 1024, (0, 0, 1024)), (64, 200, 512, (256, 0, 256)),
     (300, 1024, 2048, (1024, 0, 1024)), (96, 640, 5120, (4096, 512, 512)),
+    (140, 131, 256, (128, 0, 128)), (300, 72, 128, (0, 128, 0)), (513, 257, 384, (128, 128, 128)),   # odd N: scalar store path
 ]
 # shapes the library runs as split-K when given a workspace (few output tiles, M > 64); each also runs unsplit
 SPLIT_SHAPES = [
