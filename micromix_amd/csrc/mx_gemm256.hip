@@ -74,29 +74,47 @@ namespace mm {
 constexpr int SPLIT_WG_FLOATS = g128::NACC * g128::NT;  // 32768 floats = 128 KiB of partial sums per workgroup
 
 __global__ void __launch_bounds__(256) splitk_reduce_kernel(GemmArgs a, int tiles_n, int total) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
+    // one thread = four consecutive lanes' copies of one accumulator register: 16-byte loads of the partial sums, and the four
+    // results are four consecutive features of one token (8-byte store)
+    const int e = (blockIdx.x * 256 + threadIdx.x) * 4;
     if (e >= total) return;
     // e = (tile, accumulator register r, thread tid of the GEMM workgroup): consecutive threads read consecutive floats
     const int tid = e & (g128::NT - 1), r = (e >> 9) & (g128::NACC - 1), tile = e >> 15;
     const float *p = a.ws + ((size_t)tile * a.splits * g128::NACC + r) * g128::NT + tid;
-    float run = 0.0f;
+    float run[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
     for (int seg = 0; seg < 3; ++seg) {
         if (a.split_first[seg + 1] == a.split_first[seg]) continue;
-        float s = 0.0f;
-        for (int q = a.split_first[seg]; q < a.split_first[seg + 1]; ++q) s += p[(size_t)q * SPLIT_WG_FLOATS];
-        s += run;
-        run = a.round_per_segment ? bf16_bits_to_f32(f32_to_bf16_bits(s)) : s;
+        float s[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int q = a.split_first[seg]; q < a.split_first[seg + 1]; ++q) {
+            const float4 v = *reinterpret_cast<const float4 *>(p + (size_t)q * SPLIT_WG_FLOATS);
+            s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float t = s[i] + run[i];
+            run[i] = a.round_per_segment ? bf16_bits_to_f32(f32_to_bf16_bits(t)) : t;
+        }
     }
     // accumulator layout of the tile kernel: wave = 2 * wm + wn owns tokens wm*32.., features wn*128..; register r of
     // MFMA tile tn = r >> 4: token (r & 3) + 8 * ((r >> 2) & 3) + 4 * (lane >> 5), feature tn*32 + (lane & 31)
     const int wave = tid >> 6, lane = tid & 63, wm = wave >> 1, wn = wave & 1;
     const int m = (tile / tiles_n) * g128::BM + wm * 32 + (r & 3) + 8 * ((r >> 2) & 3) + 4 * (lane >> 5);
-    const int n = (tile % tiles_n) * g128::BN + wn * 128 + (r >> 4) * 32 + (lane & 31);
-    if (m < a.M && n < a.N) {
-        uint32_t b = f32_to_bf16_bits(run);
-        if (a.bias != nullptr) b = f32_to_bf16_bits(bf16_bits_to_f32(b) + bf16_bits_to_f32(a.bias[n]));
-        a.D[(size_t)m * a.N + n] = (uint16_t)b;
+    const int n = (tile % tiles_n) * g128::BN + wn * 128 + (r >> 4) * 32 + (lane & 31);   // lane & 3 == 0
+    if (m >= a.M) return;
+    uint32_t b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        b[i] = f32_to_bf16_bits(run[i]);
+        if (a.bias != nullptr && n + i < a.N) b[i] = f32_to_bf16_bits(bf16_bits_to_f32(b[i]) + bf16_bits_to_f32(a.bias[n + i]));
+    }
+    uint16_t *dst = a.D + (size_t)m * a.N + n;
+    if ((a.N & 3) == 0 && n + 3 < a.N) {
+        *reinterpret_cast<uint2 *>(dst) = make_uint2(b[0] | (b[1] << 16), b[2] | (b[3] << 16));
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (n + i < a.N) dst[i] = (uint16_t)b[i];
     }
 }
 
@@ -199,7 +217,7 @@ hipError_t launch_mx_gemm256(const GemmArgs &a, bool w4, hipStream_t stream) {
                               : launch_tile(g128::mx_gemm256_kernel<false, true>, done[5], g128::Lds<false>::TOTAL, tiles128 * b.splits, g128::NT, b, stream);
             if (e != hipSuccess) return e;
             const int total = tiles128 * SPLIT_WG_FLOATS;
-            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, b, tn, total);
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((total / 4 + 255) / 256), dim3(256), 0, stream, b, tn, total);
             return hipGetLastError();
         }
     }
