@@ -154,6 +154,7 @@ int mm_matmul_ws(const uint8_t *AN, const uint8_t *BN, const uint8_t *AS, const 
     a.ws = (float *)workspace;
     a.ws_bytes = workspace ? workspace_bytes : 0;
     a.splits = 0;
+    a.n_tile0 = a.n_tiles = 0;
     a.force_split = (flags & MM_SPLIT_K_ALWAYS) ? 1 : 0;
     a.split_first[0] = a.split_first[1] = a.split_first[2] = a.split_first[3] = 0;
     hipError_t e = mm::launch_mx_gemm(a, wmode == MM_W_FP4, (hipStream_t)stream);

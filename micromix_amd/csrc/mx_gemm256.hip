@@ -224,7 +224,32 @@ hipError_t launch_mx_gemm256(const GemmArgs &a, bool w4, hipStream_t stream) {
     // 256-row tiles move the fewest L2->LDS bytes per flop; use them when they (nearly) fill the 256 CUs, otherwise halve
     // the tile height so that twice as many workgroups exist.
     static const int force = env_int("MICROMIX_GEMM_TILE", 0);   // kernel-developer override: 256 or 128
+    static const int tail_split = env_int("MICROMIX_GEMM_TAIL", 1);
     const bool use128 = force == 128 || (force != 256 && tiles256 < 192);
+    // Tail balancing: one workgroup per CU, so tiles256 = q * CUs + R runs q + 1 rounds and the last one leaves CUs idle.
+    // When R <= CUs / 2 and R is a whole number of tile columns, those columns are run as 128-row tiles instead (2R
+    // workgroups of half the work: the last round takes half the time).  gate/up at M = 4096: 896 tiles = 3.5 rounds.
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = 256;
+    }
+    const int tm256 = (a.M + 255) / 256, rem = tiles256 % cus;
+    if (!use128 && tail_split && force == 0 && tiles256 > cus && rem > 0 && 2 * rem <= cus && rem % tm256 == 0) {
+        const int c = rem / tm256;
+        GemmArgs lo = a, hi = a;
+        lo.n_tile0 = 0;
+        lo.n_tiles = tn - c;
+        hi.n_tile0 = tn - c;
+        hi.n_tiles = c;
+        hipError_t e = w4 ? launch_tile(g256::mx_gemm256_kernel<true, false>, done[0], g256::Lds<true>::TOTAL, tm256 * (tn - c), g256::NT, lo, stream)
+                          : launch_tile(g256::mx_gemm256_kernel<false, false>, done[1], g256::Lds<false>::TOTAL, tm256 * (tn - c), g256::NT, lo, stream);
+        if (e != hipSuccess) return e;
+        const int tm128 = (a.M + 127) / 128;
+        return w4 ? launch_tile(g128::mx_gemm256_kernel<true, false>, done[2], g128::Lds<true>::TOTAL, tm128 * c, g128::NT, hi, stream)
+                  : launch_tile(g128::mx_gemm256_kernel<false, false>, done[3], g128::Lds<false>::TOTAL, tm128 * c, g128::NT, hi, stream);
+    }
     if (!use128) {
         if (w4) return launch_tile(g256::mx_gemm256_kernel<true, false>, done[0], g256::Lds<true>::TOTAL, tiles256, g256::NT, a, stream);
         return launch_tile(g256::mx_gemm256_kernel<false, false>, done[1], g256::Lds<false>::TOTAL, tiles256, g256::NT, a, stream);

@@ -20,6 +20,7 @@ struct GemmArgs {
     float *ws;              // split-K workspace (NULL: never split), see mm_matmul_ws
     size_t ws_bytes;
     int force_split;        // MM_SPLIT_K_ALWAYS
+    int n_tile0, n_tiles;   // launcher: this launch covers 256-feature tile columns [n_tile0, n_tile0 + n_tiles) (0, 0 = all)
     int splits;             // filled in by the launcher when it splits K
     int split_first[4];     // splits [split_first[i], split_first[i+1]) work on segment i
     hipEvent_t ev_start, ev_stop;   // diagnostics only (mm_diag_set_kernel_events): recorded at the GEMM dispatch itself

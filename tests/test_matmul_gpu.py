@@ -211,6 +211,28 @@ def test_full_size_properties(dev):
             check_gemm(bits_from_t(d1)[rows], qx, qw, "reference", label=f"4096^3 {split}")
 
 
+def test_tail_balanced_launch(dev):
+    """more 256x256 tiles than CUs with a small remainder: the launcher runs the last tile columns as 128-row tiles (two
+    launches).  M=2048, N=8448 -> 8 x 33 = 264 tiles = 256 + one column.  Oracle on a row sample, every column."""
+    import torch
+    rng = np.random.default_rng(4)
+    M, N, K, split = 2048, 8448, 256, (128, 0, 128)
+    xb = make_inputs(rng, M, K)
+    wb = make_inputs(rng, N, K, "weight")
+    idx = rng.permutation(K).astype(np.int16)
+    x, w, tidx = t_from_bits(xb, dev), t_from_bits(wb, dev), torch.from_numpy(idx).to(dev)
+    a = mixedgemm.reorder_quantize_x(x, tidx, *split)
+    b = mixedgemm.reorder_quantize_w4(w, tidx, *split)
+    d = mixedgemm.matmul(a[0], b[0], a[1], b[1], a[2], b[2], a[3], b[3], a[4], b[4], a[5], b[5])
+    rows = np.sort(np.concatenate([rng.choice(M, 40, replace=False), [0, 127, 128, 255, 256, M - 1]]))
+    qx = o.reorder_quantize(xb[rows], idx, *split, "x")
+    check_gemm(bits_from_t(d)[rows], qx, [u8(t) for t in b], "reference", label="tail-balanced 2048x8448")
+    # a row block computed alone (one launch, 128-row tiles) equals the same rows of the two-launch product
+    sub = mixedgemm.reorder_quantize_x(x[300:500].contiguous(), tidx, *split)
+    assert torch.equal(mixedgemm.matmul(sub[0], b[0], sub[1], b[1], sub[2], b[2], sub[3], b[3], sub[4], b[4], sub[5], b[5],
+                                        split_k=False), d[300:500])
+
+
 def test_errors(dev):
     import torch
     z = lambda *s: torch.zeros(s, dtype=torch.uint8, device=dev)
