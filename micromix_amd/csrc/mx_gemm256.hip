@@ -35,6 +35,9 @@
 #ifndef MM_STAGING
 #define MM_STAGING 0  // 0: LDS-DMA operand pipeline, 1: VGPR-staged (see run_segment_v)
 #endif
+#ifndef MM_EPI_DIRECT
+#define MM_EPI_DIRECT 0  // 1: epilogue stores 8 bytes per lane straight from registers (no LDS transpose)
+#endif
 #ifndef MM_NT_STORE
 #define MM_NT_STORE 0
 #endif

@@ -52,3 +52,30 @@ def test_prequantized_tuple_input(dev):
         assert torch.equal(q(shared), q(x))
     with pytest.raises(RuntimeError, match="different"):
         QLinearLayer(torch.nn.Linear(k, 128, bias=False, dtype=torch.bfloat16).to(dev), p8_num=256, p6_num=128, reorder_index=idx)(shared)
+
+
+@pytest.mark.parametrize("m", (1, 48, 200))
+def test_fused_layers_equal_separate_layers(dev, m):
+    """FusedQLinear([q, k, v]) = the three layers, bit for bit (bias on some, none on others)."""
+    import torch
+    from micromix_amd.qlinear import FusedQLinear
+    g = torch.Generator().manual_seed(5)
+    k, split = 1024, (512, 128, 384)
+    idx = torch.randperm(k, generator=g)
+    layers = []
+    for n, bias in ((512, True), (128, False), (256, True)):
+        lin = torch.nn.Linear(k, n, bias=bias, dtype=torch.bfloat16)
+        with torch.no_grad():
+            lin.weight.copy_((torch.randn((n, k), generator=g) * 0.05).to(torch.bfloat16))
+            if bias:
+                lin.bias.copy_(torch.randn((n,), generator=g).to(torch.bfloat16))
+        layers.append(QLinearLayer(lin.to(dev), p8_num=split[2], p6_num=split[1], reorder_index=idx))
+    fused = FusedQLinear(layers)
+    x = torch.randn((1, m, k), generator=g).to(torch.bfloat16).to(dev)
+    outs = fused(x)
+    for layer, y in zip(layers, outs):
+        ref = layer(x)
+        if layer.bias is None and fused.bias is not None:
+            # the fused bias vector holds zeros for this layer: y = bf16(bf16(acc) + 0) = the same value
+            pass
+        assert torch.equal(y, ref)

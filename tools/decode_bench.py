@@ -4,7 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 from micromix_amd.graph import GraphedForward
-from micromix_amd.qlinear import QLinearLayer
+from micromix_amd.qlinear import FusedQLinear, QLinearLayer
 dev = torch.device("cuda:0")
 g = torch.Generator().manual_seed(0)
 K, split = 4096, (2048, 128, 1920)
@@ -18,11 +18,13 @@ for M in (1, 16, 64):
     def eager():
         return [l(x) for l in qkv]
     graphed = GraphedForward(qkv, x)
-    for name, f in (("eager", eager), ("hipGraph", lambda: graphed(x))):
+    fused = FusedQLinear(qkv)
+    gfused = GraphedForward([fused], x)
+    for name, f in (("eager", eager), ("hipGraph", lambda: graphed(x)), ("fused qkv", lambda: fused(x)), ("fused+graph", lambda: gfused(x))):
         for _ in range(20): f()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(300): f()
         torch.cuda.synchronize()
         us = (time.perf_counter() - t0) / 300 * 1e6
-        print(f"q+k+v projections, M={M:3d}, {name:8s}: {us:7.1f} us per step  ({M/us*1e6:,.0f} tokens/s)", flush=True)
+        print(f"q+k+v projections, M={M:3d}, {name:11s}: {us:7.1f} us per step  ({M/us*1e6:,.0f} tokens/s)", flush=True)
