@@ -156,6 +156,20 @@ int mm_matmul_ws(const uint8_t *AN, const uint8_t *BN, const uint8_t *AS, const 
                  const void *bias_bf16, void *D_bf16, void *workspace, size_t workspace_bytes, mm_stream_t stream);
 
 /*
+ * QLinearLayer.forward for decode-sized inputs in ONE launch (reference: qLinearLayer.py:58-74 = reorder_quantize_x + matmul
+ * (+ bias)): every workgroup quantizes the M activation rows into LDS itself and then streams its weight rows.  Bit-identical to
+ * mm_reorder_quantize(MM_QUANT_MIXED) followed by mm_matmul.  mm_qlinear_decode_supported() returns 0 when the shape cannot run
+ * (needs 1 <= M <= 8 and the quantized rows in LDS; mm_qlinear_decode then returns MM_ERR_UNSUPPORTED), 1 when it can, 2 when it
+ * can and is expected to be faster than the two calls (every workgroup repeats the quantization, so many rows x many
+ * workgroup rounds lose).
+ *   X_bf16 [M, KN+KS+KO] bf16, reorder_index [K] int16, B / SFB as mm_matmul, flags MM_ROUND_*, bias optional, D [M, N] bf16
+ */
+int mm_qlinear_decode_supported(int M, int N, int KN, int KS, int KO);
+int mm_qlinear_decode(const void *X_bf16, const int16_t *reorder_index, const uint8_t *BN, const uint8_t *BS, const uint8_t *BO,
+                      const uint8_t *SFBN, const uint8_t *SFBS, const uint8_t *SFBO, int M, int N, int KN, int KS, int KO,
+                      int wmode, int flags, const void *bias_bf16, void *D_bf16, mm_stream_t stream);
+
+/*
  * Hardware diagnostics (not on the product path; used by the GPU tests to pin register
  * layouts and the oracle's encoders against the CDNA4 hardware).
  *   mm_diag_mfma: one wave issues one v_mfma_scale_f32_{32x32x64,16x16x128}_f8f6f4.

@@ -17,7 +17,7 @@ EXPORTS = (
     "mm_version", "mm_strerror", "mm_last_error",
     "mm_sf_bytes_x", "mm_sf_bytes_w", "mm_sf_offset",
     "mm_reorder_quantize", "mm_reorder_quantize_gather", "mm_activate_quantize", "mm_downproj_quantize", "mm_matmul",
-    "mm_matmul_ws", "mm_matmul_workspace_bytes", "mm_rmsnorm_quantize",
+    "mm_matmul_ws", "mm_matmul_workspace_bytes", "mm_rmsnorm_quantize", "mm_qlinear_decode", "mm_qlinear_decode_supported",
     "mm_diag_mfma", "mm_diag_hw_convert", "mm_diag_mfma_rate", "mm_diag_l2_bw", "mm_diag_set_clock_buffer",
     "mm_diag_set_kernel_events",
 )
@@ -70,6 +70,10 @@ def load():
     lib.mm_matmul.argtypes = [vp] * 12 + [i] * 7 + [vp, vp, vp]
     lib.mm_rmsnorm_quantize.restype = i
     lib.mm_rmsnorm_quantize.argtypes = [vp, vp, ctypes.c_float, i, i, vp, i, i, i, i] + [vp] * 7
+    lib.mm_qlinear_decode.restype = i
+    lib.mm_qlinear_decode.argtypes = [vp] * 8 + [i] * 7 + [vp, vp, vp]
+    lib.mm_qlinear_decode_supported.restype = i
+    lib.mm_qlinear_decode_supported.argtypes = [i] * 5
     lib.mm_matmul_ws.restype = i
     lib.mm_matmul_ws.argtypes = [vp] * 12 + [i] * 7 + [vp, vp, vp, ctypes.c_size_t, vp]
     lib.mm_matmul_workspace_bytes.restype = ctypes.c_size_t

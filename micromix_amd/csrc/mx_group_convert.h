@@ -137,4 +137,34 @@ __device__ __forceinline__ void convert_group(const uint32_t (&v)[16], float sca
     }
 }
 
+// One 32-element group: gather (two bf16 per VGPR), block absmax, UE8M0 scale, convert, pack, store; returns the
+// scale byte.  `ix` holds BYTE offsets into the staged row (index << 1), two per register.
+// Conversion uses the CDNA4 MX converters (v_cvt_scalef32_pk_fp4_bf16 / _pk_fp8_bf16 / _pk32_bf6_bf16: dst =
+// RNE(src / scale), saturating) -- tests/test_hw_gpu.py checks them code-for-code against the oracle's encoders for every
+// finite bf16, and tests/test_quantize_gpu.py checks the kernel's bytes.
+template <int EL>
+__device__ __forceinline__ uint32_t quantize_group(const uint8_t *__restrict__ row, const uint32_t (&ix)[16],
+                                                   uint8_t *__restrict__ out) {
+    uint32_t v[16];  // v[i] = {element 2i (low half), element 2i+1 (high half)}
+    us2 amax2 = {0, 0};
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const uint32_t lo = *reinterpret_cast<const uint16_t *>(row + (ix[i] & 0xFFFFu));
+        const uint32_t hi = *reinterpret_cast<const uint16_t *>(row + (ix[i] >> 16));
+        v[i] = lo | (hi << 16);
+        const uint32_t mag = v[i] & 0x7FFF7FFFu;
+        us2 m;
+        __builtin_memcpy(&m, &mag, 4);
+        amax2 = __builtin_elementwise_max(amax2, m);
+    }
+    const uint32_t amax = amax2[0] > amax2[1] ? amax2[0] : amax2[1];
+    const int e = scale_exponent<EL>(amax << 16);
+    if (e == -127) {
+        quantize_group_tiny<EL>(v, out);
+        return 0u;
+    }
+    convert_group<EL>(v, __uint_as_float((uint32_t)(127 + e) << 23), out);  // scale 2^e, a normal fp32
+    return (uint32_t)(e + 127);
+}
+
 }  // namespace mm

@@ -35,6 +35,10 @@ hipError_t launch_direct_quantize(const void *A, const void *B, int rows, int KN
 hipError_t launch_rmsnorm_quantize(const void *src, const void *weight, float eps, int rows, int K, const int16_t *idx, int KN,
                                    int KS, int KO, bool integer_round, uint8_t *oN, uint8_t *oS, uint8_t *oO, uint8_t *sfN,
                                    uint8_t *sfS, uint8_t *sfO, hipStream_t stream);
+int qlinear_decode_supported(int M, int N, const int K[3]);
+hipError_t launch_qlinear_decode(const void *X, const int16_t *idx, const uint8_t *const W[3], const uint8_t *const SFW[3],
+                                 int M, int N, const int K[3], bool w4, int round_per_segment, const void *bias, void *D,
+                                 hipStream_t stream);
 hipError_t launch_mx_gemm(const GemmArgs &a, bool w4, hipStream_t stream);
 hipError_t launch_mx_gemm256(const GemmArgs &a, bool w4, hipStream_t stream);
 hipError_t launch_mx_gemm_skinny(const GemmArgs &a, bool w4, hipStream_t stream);

@@ -1,0 +1,271 @@
+// Decode-sized QLinearLayer.forward in ONE launch (M <= 8 token rows): reorder + quantize of the activations fused into the
+// weight-streaming GEMM of mx_gemm_skinny.hip.
+//
+// Reference semantics: reorder_quantize_x (mgemm/src/reorder.cu:94-269) followed by matmul (gemm.cu:26-78) (+ bias,
+// qLinearLayer.py:58-74) -- the same arithmetic as the two separate kernels, bit for bit (the group quantizer is the shared
+// quantize_group of mx_group_convert.h, the GEMM part follows mx_gemm_skinny.hip).
+//
+// Why: at M = 1 the quantize kernel (4.9 us) and the GEMM (6 us) are both at their launch + one-memory-round-trip floor, so
+// the pair costs two floors.  Here every workgroup (32 output features, 8 waves) first quantizes the M activation rows into
+// LDS by itself -- the rows are a few KB, re-reading them from L2 in every workgroup is free compared with a second launch --
+// and then runs the skinny GEMM with the activation fragments and scales coming from LDS and only the weights from HBM.
+#include "mx_group_convert.h"
+#include "mx_kernels.h"
+
+namespace mm {
+namespace decode {
+
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v2i __attribute__((ext_vector_type(2)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+constexpr int NT = 512, NW = 8, BN = 32;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const uint8_t *base, unsigned bytes) {
+    const unsigned long long v = (unsigned long long)base;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    const unsigned nb = __builtin_amdgcn_readfirstlane(bytes);
+    return __builtin_amdgcn_make_buffer_rsrc((void *)(((unsigned long long)hi << 32) | lo), 0, (int)nb, 0x00020000);
+}
+
+template <int EL> struct G { static constexpr int BYTES = EL == EL_FP8 ? 128 : (EL == EL_FP6 ? 96 : 64); };
+
+// weight fragment from global memory (as mx_gemm_skinny.hip)
+template <int EL>
+__device__ __forceinline__ v8i load_wfrag(__amdgpu_buffer_rsrc_t rsrc, int rowoff, int slab, int h, int kb) {
+    const int so = slab * G<EL>::BYTES;
+    v8i r = {0, 0, 0, 0, 0, 0, 0, 0};
+    if constexpr (EL == EL_FP8) {
+        const v4i lo = __builtin_amdgcn_raw_buffer_load_b128(rsrc, rowoff + (4 * h + kb) * 16, so, 0);
+        const v4i hi = __builtin_amdgcn_raw_buffer_load_b128(rsrc, rowoff + (4 * h + 2 + kb) * 16, so, 0);
+        r = v8i{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    } else if constexpr (EL == EL_FP4) {
+        const v4i v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, rowoff + (2 * h + kb) * 16, so, 0);
+        r = v8i{v[0], v[1], v[2], v[3], 0, 0, 0, 0};
+    } else {
+        const int o = rowoff + (2 * h + kb) * 24;
+        const v2i a = __builtin_amdgcn_raw_buffer_load_b64(rsrc, o, so, 0);
+        const v2i b = __builtin_amdgcn_raw_buffer_load_b64(rsrc, o + 8, so, 0);
+        const v2i c = __builtin_amdgcn_raw_buffer_load_b64(rsrc, o + 16, so, 0);
+        r = v8i{a[0], a[1], b[0], b[1], c[0], c[1], 0, 0};
+    }
+    return r;
+}
+
+// activation fragment from the LDS copy of the quantized row (`p` = row base + slab * BYTES); same register layouts
+template <int EL>
+__device__ __forceinline__ v8i lds_xfrag(const uint8_t *p, int h, int kb) {
+    v8i r = {0, 0, 0, 0, 0, 0, 0, 0};
+    if constexpr (EL == EL_FP8) {
+        const uint4 lo = *reinterpret_cast<const uint4 *>(p + (4 * h + kb) * 16);
+        const uint4 hi = *reinterpret_cast<const uint4 *>(p + (4 * h + 2 + kb) * 16);
+        r = v8i{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
+    } else if constexpr (EL == EL_FP4) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(p + (2 * h + kb) * 16);
+        r = v8i{(int)v.x, (int)v.y, (int)v.z, (int)v.w, 0, 0, 0, 0};
+    } else {
+        const uint2 *q = reinterpret_cast<const uint2 *>(p + (2 * h + kb) * 24);
+        const uint2 a = q[0], b = q[1], c = q[2];
+        r = v8i{(int)a.x, (int)a.y, (int)b.x, (int)b.y, (int)c.x, (int)c.y, 0, 0};
+    }
+    return r;
+}
+
+struct Args {
+    const uint16_t *X;      // [M, K] bf16
+    const int16_t *idx;     // [K]
+    const uint8_t *W[3];    // packed weight segments
+    const uint8_t *SFW[3];
+    int K[3];
+    int M, N;
+    int sfw_row_tiles;
+    int round_per_segment;
+    const uint16_t *bias;
+    uint16_t *D;
+    int stage_rows;         // activation rows staged in LDS at a time (launcher: as many as fit)
+};
+
+// this wave's slabs of one segment; xl = LDS base of the segment's quantized rows (pitch xp bytes), sl = LDS base of the
+// segment's scale bytes (pitch sp bytes per row, 4 consecutive bytes per slab)
+template <int XEL, int WEL>
+__device__ __forceinline__ void run_segment(v16f &acc, const uint8_t *xl, int xp, const uint8_t *sl, int sp, const uint8_t *W,
+                                            const uint8_t *SFW, int nslab, int M, int N, int n0, int sfw_tiles) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int li = lane & 31, kb = lane >> 5;
+    const int wrb = nslab * G<WEL>::BYTES;
+    int wrows = N - n0;
+    wrows = wrows > BN ? BN : wrows;
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(W + (size_t)n0 * wrb, (unsigned)wrows * (unsigned)wrb);
+    const __amdgpu_buffer_rsrc_t rsw = make_rsrc(SFW, (unsigned)sfw_tiles * (unsigned)nslab * 512u);
+    const int n = n0 + li;
+    const int sfw_off = (n >> 7) * nslab * 512 + (n & 31) * 16 + ((n >> 5) & 3) * 4;
+    const bool valid = li < M;   // MFMA rows = tokens; rows past M are zero
+    const uint8_t *xrow = xl + (valid ? li : 0) * xp;
+    const uint8_t *srow = sl + (valid ? li : 0) * sp;
+    const int sh = 8 * kb;
+    for (int s = wave; s < nslab; s += NW) {
+        const int sw = __builtin_amdgcn_raw_buffer_load_b32(rsw, sfw_off, s * 512, 0) >> sh;
+        v8i wf[2], xf[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) wf[h] = load_wfrag<WEL>(rw, li * wrb, s, h, kb);
+        int sx = 0;
+        const v8i zero = {0, 0, 0, 0, 0, 0, 0, 0};
+        xf[0] = xf[1] = zero;
+        if (valid) {
+            sx = (int)(*reinterpret_cast<const uint32_t *>(srow + 4 * s) >> sh);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) xf[h] = lds_xfrag<XEL>(xrow + s * G<XEL>::BYTES, h, kb);
+        }
+        acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(xf[0], wf[0], acc, ElemTraits<XEL>::HW, ElemTraits<WEL>::HW, 0, sx, 0, sw);
+        acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(xf[1], wf[1], acc, ElemTraits<XEL>::HW, ElemTraits<WEL>::HW, 2, sx, 2, sw);
+    }
+}
+
+template <bool W4>
+__global__ void __launch_bounds__(NT) qlinear_decode_kernel(Args a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];   // [row stage | opN | opS | opO | scales]
+    __shared__ float red[NW][16][64];
+    const int Kt = a.K[0] + a.K[1] + a.K[2], Gt = Kt >> 5;
+    const int gN = a.K[0] >> 5, gS = a.K[1] >> 5;
+    const int pN = a.K[0] >> 1, pS = (a.K[1] >> 2) * 3, pO = a.K[2];      // packed bytes per row and segment
+    uint8_t *stage = smem;
+    uint8_t *opN = stage + (size_t)a.stage_rows * Kt * 2, *opS = opN + a.M * pN, *opO = opS + a.M * pS;
+    uint8_t *scales = opO + a.M * pO;
+
+    // ---- phase 1: quantize the M activation rows into LDS (reorder.cu:94-269 per group, shared quantize_group) ----
+    // stage_rows rows are staged at a time and their (row, group) pairs are spread over all 512 threads
+    for (int r0 = 0; r0 < a.M; r0 += a.stage_rows) {
+        const int nr = (a.M - r0) < a.stage_rows ? (a.M - r0) : a.stage_rows;
+        const uint4 *grow = reinterpret_cast<const uint4 *>(a.X + (size_t)r0 * Kt);
+        for (int c = threadIdx.x; c < nr * (Kt >> 3); c += NT) reinterpret_cast<uint4 *>(stage)[c] = grow[c];
+        __syncthreads();
+        for (int t = threadIdx.x; t < nr * Gt; t += NT) {
+            const int rr = t / Gt, g = t - rr * Gt, r = r0 + rr;
+            const uint8_t *row = stage + (size_t)rr * Kt * 2;
+            uint32_t ix[16];
+            const uint4 *p = reinterpret_cast<const uint4 *>(a.idx + (size_t)g * 32);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint4 q = p[i];
+                ix[4 * i] = (q.x << 1) & 0xFFFEFFFEu;
+                ix[4 * i + 1] = (q.y << 1) & 0xFFFEFFFEu;
+                ix[4 * i + 2] = (q.z << 1) & 0xFFFEFFFEu;
+                ix[4 * i + 3] = (q.w << 1) & 0xFFFEFFFEu;
+            }
+            uint32_t byte;
+            if (g < gN) byte = quantize_group<EL_FP4>(row, ix, opN + r * pN + g * 16);
+            else if (g < gN + gS) byte = quantize_group<EL_FP6>(row, ix, opS + r * pS + (g - gN) * 24);
+            else byte = quantize_group<EL_FP8>(row, ix, opO + r * pO + (g - gN - gS) * 32);
+            scales[r * Gt + g] = (uint8_t)byte;
+        }
+        __syncthreads();
+    }
+
+    // ---- phase 2: weight-streaming GEMM, 32 features per workgroup, K split over the 8 waves (mx_gemm_skinny.hip) ----
+    const int n0 = blockIdx.x * BN;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nseg[3] = {a.K[0] >> 7, a.K[1] >> 7, a.K[2] >> 7};
+    v16f accN, accS, accO;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) accN[i] = accS[i] = accO[i] = 0.0f;
+    if (nseg[0]) run_segment<EL_FP4, EL_FP4>(accN, opN, pN, scales, Gt, a.W[0], a.SFW[0], nseg[0], a.M, a.N, n0, a.sfw_row_tiles);
+    if (nseg[1]) run_segment<EL_FP6, (W4 ? EL_FP4 : EL_FP6)>(accS, opS, pS, scales + gN, Gt, a.W[1], a.SFW[1], nseg[1], a.M, a.N, n0, a.sfw_row_tiles);
+    if (nseg[2]) run_segment<EL_FP8, (W4 ? EL_FP4 : EL_FP8)>(accO, opO, pO, scales + gN + gS, Gt, a.W[2], a.SFW[2], nseg[2], a.M, a.N, n0, a.sfw_row_tiles);
+
+    // cross-wave reduction per segment with the reference's rounding chain (as mx_gemm_skinny.hip)
+    float run[2] = {0.0f, 0.0f};
+    auto reduce = [&](const v16f &acc) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 16; ++i) red[wave][i][lane] = acc[i];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int e = threadIdx.x + NT * j;
+            float s = 0.0f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) s += (&red[w][0][0])[e];
+            s += run[j];
+            run[j] = a.round_per_segment ? bf16_bits_to_f32(f32_to_bf16_bits(s)) : s;
+        }
+    };
+    if (nseg[0]) reduce(accN);
+    if (nseg[1]) reduce(accS);
+    if (nseg[2]) reduce(accO);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int e = threadIdx.x + NT * j;
+        const int l = e & 63, i = (e >> 6) & 15;
+        const int m = (i & 3) + 8 * (i >> 2) + 4 * (l >> 5);
+        const int n = n0 + (l & 31);
+        if (m < a.M && n < a.N) {
+            uint32_t b = f32_to_bf16_bits(run[j]);
+            if (a.bias != nullptr) b = f32_to_bf16_bits(bf16_bits_to_f32(b) + bf16_bits_to_f32(a.bias[n]));
+            a.D[(size_t)m * a.N + n] = (uint16_t)b;
+        }
+    }
+}
+
+}  // namespace decode
+
+// dynamic LDS: the quantized rows and scales of all M rows + as many staged bf16 rows as fit next to the 32 KB reduction buffer
+constexpr size_t DECODE_LDS_MAX = 126 * 1024;
+static size_t decode_operand_bytes(int M, const int K[3]) {   // quantized rows + their scale bytes
+    const size_t Kt = (size_t)K[0] + K[1] + K[2];
+    return (size_t)M * (K[0] / 2 + K[1] / 4 * 3 + K[2] + Kt / 32);
+}
+
+// 0: cannot run; 1: can run; 2: can run and is expected to beat quantize + GEMM.  Every workgroup repeats the quantization, in
+// ceil(M * K/32 / 512) passes of ~1.4 us, and N/32 workgroups take ceil(N/32 / CUs) rounds; measured on MI355X the fused
+// kernel wins while rounds * passes <= 2 (q/o up to M = 8, gate/up and down up to M = 2-4) and loses beyond.
+int qlinear_decode_supported(int M, int N, const int K[3]) {
+    const size_t Kt = (size_t)K[0] + K[1] + K[2];
+    if (M < 1 || M > 8 || Kt * 2 + decode_operand_bytes(M, K) > DECODE_LDS_MAX) return 0;   // at least one staged row must fit
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = 256;
+    }
+    const int rounds = ((N + decode::BN - 1) / decode::BN + cus - 1) / cus;
+    const int passes = (int)((M * (Kt / 32) + decode::NT - 1) / decode::NT);
+    return rounds * passes <= 2 ? 2 : 1;
+}
+
+hipError_t launch_qlinear_decode(const void *X, const int16_t *idx, const uint8_t *const W[3], const uint8_t *const SFW[3],
+                                 int M, int N, const int K[3], bool w4, int round_per_segment, const void *bias, void *D,
+                                 hipStream_t stream) {
+    using namespace decode;
+    static bool done[2] = {false, false};
+    Args a;
+    a.X = (const uint16_t *)X;
+    a.idx = idx;
+    for (int i = 0; i < 3; ++i) {
+        a.W[i] = W[i];
+        a.SFW[i] = SFW[i];
+        a.K[i] = K[i];
+    }
+    a.M = M;
+    a.N = N;
+    a.sfw_row_tiles = (N + 127) / 128;
+    a.round_per_segment = round_per_segment;
+    a.bias = (const uint16_t *)bias;
+    a.D = (uint16_t *)D;
+    const size_t Kt = (size_t)K[0] + K[1] + K[2], ops = decode_operand_bytes(M, K);
+    int stage_rows = (int)((DECODE_LDS_MAX - ops) / (Kt * 2));
+    stage_rows = stage_rows > M ? M : stage_rows;
+    a.stage_rows = stage_rows;
+    const size_t lds = (size_t)stage_rows * Kt * 2 + ops;
+    auto kern = w4 ? qlinear_decode_kernel<true> : qlinear_decode_kernel<false>;
+    if (!done[w4 ? 0 : 1]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DECODE_LDS_MAX);
+        if (e != hipSuccess) return e;
+        done[w4 ? 0 : 1] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((N + BN - 1) / BN), dim3(NT), lds, stream, a);
+    return hipGetLastError();
+}
+
+}  // namespace mm

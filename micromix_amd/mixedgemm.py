@@ -28,7 +28,7 @@ import torch
 from . import _lib
 
 __all__ = ["matmul", "reorder_quantize_x", "reorder_quantize_w", "reorder_quantize_w4", "activate_quantize_x",
-           "downproj_quantize_w", "downproj_quantize_w4", "rmsnorm_quantize_x"]
+           "downproj_quantize_w", "downproj_quantize_w4", "rmsnorm_quantize_x", "qlinear_decode", "qlinear_decode_supported"]
 
 
 def _stream_ptr(device) -> int:
@@ -214,6 +214,56 @@ def matmul(AN, BN, AS, BS, AO, BO, SFAN, SFBN, SFAS, SFBS, SFAO, SFBO, *, bias=N
                               ws_bytes, _stream_ptr(dev))
     if st:
         _lib.check(st, "matmul")
+    return out
+
+
+def qlinear_decode_supported(M, N, KN, KS, KO):
+    """0: `qlinear_decode` cannot run this shape (needs 1 <= M <= 8 and the quantized rows in LDS); 1: it can; 2: it can and is
+    expected to be faster than reorder_quantize_x + matmul."""
+    return int(_lib.load().mm_qlinear_decode_supported(int(M), int(N), int(KN), int(KS), int(KO)))
+
+
+def qlinear_decode(X, reorder_index, BN, BS, BO, SFBN, SFBS, SFBO, KN, KS, KO, *, bias=None, rounding="reference", out=None):
+    """reorder_quantize_x + matmul (+ bias) of `QLinearLayer.forward` (qLinearLayer.py:58-74) as ONE launch for M <= 8 rows.
+
+    Not an export of the reference module: it is what the reference's forward computes, fused for decode, and bit-identical
+    to the two-op path.  X [M, K] bf16; B / SFB are the layer's packed weights; returns [M, N] bf16.
+    """
+    lib = _lib.load()
+    dev = X.device
+    index = dev.index
+    if not (X.is_cuda and _ok(X, torch.bfloat16, index) and _ok(reorder_index, torch.int16, index)):
+        _check_tensor(X, "X", torch.bfloat16)
+        _check_tensor(reorder_index, "reorder_index", torch.int16, dev)
+    for n, t in (("BN", BN), ("BS", BS), ("BO", BO), ("SFBN", SFBN), ("SFBS", SFBS), ("SFBO", SFBO)):
+        if not _ok(t, torch.uint8, index):
+            _check_tensor(t, n, torch.uint8, dev)
+    KN, KS, KO = int(KN), int(KS), int(KO)
+    M, K = X.shape
+    N = BN.size(0)
+    if K != KN + KS + KO or reorder_index.numel() != K:
+        _lib.check(_lib.MM_ERR_BAD_SPLIT, "reorder_quantize_x")
+    same = BS.size(1) == KS // 4 * 3 and BO.size(1) == KO
+    w4 = BS.size(1) == KS // 2 and BO.size(1) == KO // 2
+    if BN.size(1) != KN // 2 or not (same or w4) or BS.size(0) != N or BO.size(0) != N:
+        raise RuntimeError("packed weights do not match (KN, KS, KO)")
+    wmode = _lib.MM_W_MATCH if same else _lib.MM_W_FP4
+    if (SFBN.numel() < _sf_bytes_w(N, KN) or SFBS.numel() < _sf_bytes_w(N, KS) or SFBO.numel() < _sf_bytes_w(N, KO)):
+        raise RuntimeError("weight scale tensors are too small")
+    flags = _lib.MM_ROUND_PER_SEGMENT if rounding == "reference" else _lib.MM_ROUND_ONCE
+    if rounding not in ("reference", "fused"):
+        raise ValueError("rounding must be 'reference' or 'fused'")
+    if bias is not None and (not _ok(bias, torch.bfloat16, index) or bias.numel() != N):
+        _check_tensor(bias, "bias", torch.bfloat16, dev)
+        raise RuntimeError("bias must have N elements")
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+    with _on_device(index):
+        st = lib.mm_qlinear_decode(_ptr(X), _ptr(reorder_index), _ptr(BN), _ptr(BS), _ptr(BO), _ptr(SFBN), _ptr(SFBS), _ptr(SFBO),
+                                   M, N, KN, KS, KO, wmode, flags, _ptr(bias) if bias is not None else None, _ptr(out),
+                                   _stream_ptr(dev))
+    if st:
+        _lib.check(st, "qlinear_decode")
     return out
 
 

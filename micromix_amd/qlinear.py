@@ -10,7 +10,36 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
+import os
+
 from . import mixedgemm
+
+# decode-sized inputs (M <= 8 rows) run quantize + GEMM as one launch; MICROMIX_DECODE_FUSED=0 keeps the two-op path
+_DECODE_FUSED = os.environ.get("MICROMIX_DECODE_FUSED", "1") != "0"
+
+
+def _forward(layer, x):
+    """shared by QLinearLayer and FusedQLinear: x tensor or pre-quantized tuple -> [M, N] bf16, bsz, q_len"""
+    bias = layer.bias
+    if isinstance(x, (tuple, list)):   # pre-quantized input (qMixtralLayer.py:292,359,509,517)
+        AN, AS, AO, SFAN, SFAS, SFAO, bsz, q_len = x
+        if AN.size(1) * 2 != layer.p4_num or AO.size(1) != layer.p8_num:
+            raise RuntimeError("pre-quantized input was produced with a different (p4, p6, p8) split")
+    else:
+        bsz, q_len, _ = x.shape
+        m = bsz * q_len
+        if _DECODE_FUSED and m <= 8 and mixedgemm.qlinear_decode_supported(m, layer.out_features, layer.p4_num, layer.p6_num, layer.p8_num) == 2:
+            if bias is not None and bias.device != x.device:
+                bias = bias.to(x.device)
+            y = mixedgemm.qlinear_decode(x.reshape(m, -1).contiguous(), layer.reorder_index, layer.BN, layer.BS, layer.BO,
+                                         layer.SFBN, layer.SFBS, layer.SFBO, layer.p4_num, layer.p6_num, layer.p8_num, bias=bias)
+            return y, bsz, q_len
+        AN, AS, AO, SFAN, SFAS, SFAO, bsz, q_len = layer.quantize_input(x)
+    if bias is not None and bias.device != AN.device:
+        bias = bias.to(AN.device)
+    y = mixedgemm.matmul(AN, layer.BN, AS, layer.BS, AO, layer.BO, SFAN, layer.SFBN, SFAS, layer.SFBS, SFAO, layer.SFBO,
+                         bias=bias)
+    return y, bsz, q_len
 
 
 def find_qlinear_layers(module, name=""):
@@ -56,17 +85,7 @@ class QLinearLayer(nn.Module):
 
     @torch.no_grad()
     def forward(self, x):
-        if isinstance(x, (tuple, list)):   # pre-quantized input (qMixtralLayer.py:292,359,509,517)
-            AN, AS, AO, SFAN, SFAS, SFAO, bsz, q_len = x
-            if AN.size(1) * 2 != self.p4_num or AO.size(1) != self.p8_num:
-                raise RuntimeError("pre-quantized input was produced with a different (p4, p6, p8) split")
-        else:
-            AN, AS, AO, SFAN, SFAS, SFAO, bsz, q_len = self.quantize_input(x)
-        bias = self.bias
-        if bias is not None and bias.device != AN.device:
-            bias = bias.to(AN.device)
-        y = mixedgemm.matmul(AN, self.BN, AS, self.BS, AO, self.BO, SFAN, self.SFBN, SFAS, self.SFBS, SFAO, self.SFBO,
-                             bias=bias)
+        y, bsz, q_len = _forward(self, x)
         return y.reshape(bsz, q_len, -1)
 
 
@@ -109,10 +128,5 @@ class FusedQLinear(nn.Module):
 
     @torch.no_grad()
     def forward(self, x):
-        if isinstance(x, (tuple, list)):
-            AN, AS, AO, SFAN, SFAS, SFAO, bsz, q_len = x
-        else:
-            AN, AS, AO, SFAN, SFAS, SFAO, bsz, q_len = self.quantize_input(x)
-        y = mixedgemm.matmul(AN, self.BN, AS, self.BS, AO, self.BO, SFAN, self.SFBN, SFAS, self.SFBS, SFAO, self.SFBO,
-                             bias=self.bias)
+        y, bsz, q_len = _forward(self, x)
         return tuple(t.reshape(bsz, q_len, -1) for t in y.split(self.splits, dim=1))

@@ -2,5 +2,5 @@
 cd "$(dirname "$0")/.."
 mkdir -p micromix_amd/lib/dbg
 for d in "$@"; do
-  hipcc --offload-arch=gfx950 -O3 -std=c++20 -fPIC -shared -fno-gpu-rdc -DMM_QDBG=$d micromix_amd/csrc/capi.hip micromix_amd/csrc/reorder_quantize.hip micromix_amd/csrc/direct_quantize.hip micromix_amd/csrc/rmsnorm_quantize.hip micromix_amd/csrc/mx_gemm.hip micromix_amd/csrc/mx_gemm256.hip micromix_amd/csrc/mx_gemm_skinny.hip micromix_amd/csrc/diag.hip -o micromix_amd/lib/dbg/lib_q$d.so 2>&1 | grep -E " error"
+  hipcc --offload-arch=gfx950 -O3 -std=c++20 -fPIC -shared -fno-gpu-rdc -DMM_QDBG=$d micromix_amd/csrc/capi.hip micromix_amd/csrc/reorder_quantize.hip micromix_amd/csrc/direct_quantize.hip micromix_amd/csrc/rmsnorm_quantize.hip micromix_amd/csrc/mx_gemm.hip micromix_amd/csrc/mx_gemm256.hip micromix_amd/csrc/mx_gemm_skinny.hip micromix_amd/csrc/qlinear_decode.hip micromix_amd/csrc/diag.hip -o micromix_amd/lib/dbg/lib_q$d.so 2>&1 | grep -E " error"
 done
