@@ -18,6 +18,45 @@ from . import mixedgemm
 _DECODE_FUSED = os.environ.get("MICROMIX_DECODE_FUSED", "1") != "0"
 
 
+class _DecodePlan:
+    """Everything about a layer that `mm_qlinear_decode` needs and that does not change between calls: validated once, so the
+    decode path costs one torch.empty and one ctypes call (~8 us of host time instead of ~20)."""
+    __slots__ = ("lib", "args", "n", "k", "split", "wmode", "device", "index", "benefit")
+
+    def __init__(self, layer):
+        from . import _lib
+        self.lib = _lib.load()
+        self.n, self.k = layer.out_features, layer.in_features
+        self.split = (layer.p4_num, layer.p6_num, layer.p8_num)
+        self.device = layer.BN.device
+        self.index = self.device.index
+        same = layer.BS.size(1) == layer.p6_num // 4 * 3 and layer.BO.size(1) == layer.p8_num
+        self.wmode = _lib.MM_W_MATCH if same else _lib.MM_W_FP4
+        ptr = lambda t: t.data_ptr() if t.numel() else None
+        self.args = (ptr(layer.reorder_index), ptr(layer.BN), ptr(layer.BS), ptr(layer.BO), ptr(layer.SFBN), ptr(layer.SFBS),
+                     ptr(layer.SFBO))
+        self.benefit = {}          # rows -> mm_qlinear_decode_supported(...) == 2
+
+    def wins(self, m):
+        w = self.benefit.get(m)
+        if w is None:
+            w = self.benefit[m] = self.lib.mm_qlinear_decode_supported(m, self.n, *self.split) == 2
+        return w
+
+    def run(self, x2d, bias):
+        out = torch.empty((x2d.size(0), self.n), dtype=torch.bfloat16, device=self.device)
+        if torch.cuda.current_device() != self.index:
+            with torch.cuda.device(self.index):
+                return self.run(x2d, bias)
+        st = self.lib.mm_qlinear_decode(x2d.data_ptr(), *self.args, x2d.size(0), self.n, *self.split, self.wmode, 0,
+                                        bias.data_ptr() if bias is not None else None, out.data_ptr(),
+                                        torch.cuda.current_stream().cuda_stream)
+        if st:
+            from . import _lib
+            _lib.check(st, "qlinear_decode")
+        return out
+
+
 def _forward(layer, x):
     """shared by QLinearLayer and FusedQLinear: x tensor or pre-quantized tuple -> [M, N] bf16, bsz, q_len"""
     bias = layer.bias
@@ -26,14 +65,18 @@ def _forward(layer, x):
         if AN.size(1) * 2 != layer.p4_num or AO.size(1) != layer.p8_num:
             raise RuntimeError("pre-quantized input was produced with a different (p4, p6, p8) split")
     else:
-        bsz, q_len, _ = x.shape
+        bsz, q_len, k = x.shape
         m = bsz * q_len
-        if _DECODE_FUSED and m <= 8 and mixedgemm.qlinear_decode_supported(m, layer.out_features, layer.p4_num, layer.p6_num, layer.p8_num) == 2:
-            if bias is not None and bias.device != x.device:
-                bias = bias.to(x.device)
-            y = mixedgemm.qlinear_decode(x.reshape(m, -1).contiguous(), layer.reorder_index, layer.BN, layer.BS, layer.BO,
-                                         layer.SFBN, layer.SFBS, layer.SFBO, layer.p4_num, layer.p6_num, layer.p8_num, bias=bias)
-            return y, bsz, q_len
+        if _DECODE_FUSED and 0 < m <= 8:
+            plan = layer.__dict__.get("_decode_plan")
+            if plan is None or plan.device != layer.BN.device:
+                plan = layer.__dict__["_decode_plan"] = _DecodePlan(layer)
+            if plan.wins(m):
+                if x.dtype is not torch.bfloat16 or x.device != plan.device or k != plan.k:
+                    raise TypeError(f"input must be a bfloat16 tensor [bsz, q_len, {plan.k}] on {plan.device}")
+                if bias is not None and bias.device != x.device:
+                    bias = bias.to(x.device)
+                return plan.run(x.reshape(m, k).contiguous(), bias), bsz, q_len
         AN, AS, AO, SFAN, SFAS, SFAO, bsz, q_len = layer.quantize_input(x)
     if bias is not None and bias.device != AN.device:
         bias = bias.to(AN.device)
