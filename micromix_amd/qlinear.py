@@ -19,9 +19,11 @@ _DECODE_FUSED = os.environ.get("MICROMIX_DECODE_FUSED", "1") != "0"
 
 
 class _DecodePlan:
-    """Everything about a layer that `mm_qlinear_decode` needs and that does not change between calls: validated once, so the
-    decode path costs one torch.empty and one ctypes call (~8 us of host time instead of ~20)."""
-    __slots__ = ("lib", "args", "n", "k", "split", "wmode", "device", "index", "benefit")
+    """Everything about a layer that the C ABI needs and that does not change between calls (weight pointers, split, weight
+    mode), validated once.  `run` is the fused decode kernel (one torch.empty + one ctypes call, ~8 us of host time instead of
+    ~20); `run_two_op` is reorder_quantize_x + matmul with ONE scratch allocation for the six quantizer outputs instead of six
+    (~12 us instead of ~34), which is what bounds the eager throughput for 8 < M < ~512."""
+    __slots__ = ("lib", "args", "n", "k", "split", "wmode", "device", "index", "benefit", "ws_bytes")
 
     def __init__(self, layer):
         from . import _lib
@@ -36,6 +38,7 @@ class _DecodePlan:
         self.args = (ptr(layer.reorder_index), ptr(layer.BN), ptr(layer.BS), ptr(layer.BO), ptr(layer.SFBN), ptr(layer.SFBS),
                      ptr(layer.SFBO))
         self.benefit = {}          # rows -> mm_qlinear_decode_supported(...) == 2
+        self.ws_bytes = {}         # rows -> mm_matmul_workspace_bytes(...)
 
     def wins(self, m):
         w = self.benefit.get(m)
@@ -57,6 +60,40 @@ class _DecodePlan:
         return out
 
 
+    def run_two_op(self, x2d, bias):
+        m = x2d.size(0)
+        kn, ks, ko = self.split
+        sizes = (m * (kn // 2), m * (ks // 4 * 3), m * ko, mixedgemm._sf_bytes_x(m, kn), mixedgemm._sf_bytes_x(m, ks),
+                 mixedgemm._sf_bytes_x(m, ko))
+        offs, total = [], 0
+        for sz in sizes:
+            offs.append(total)
+            total += (sz + 255) & ~255
+        ws_bytes = self.ws_bytes.get(m)
+        if ws_bytes is None:
+            ws_bytes = self.ws_bytes[m] = self.lib.mm_matmul_workspace_bytes(m, self.n, kn, ks, ko, self.wmode, 0) if m > 64 else 0
+        if torch.cuda.current_device() != self.index:
+            with torch.cuda.device(self.index):
+                return self.run_two_op(x2d, bias)
+        # one scratch tensor: quantizer outputs + split-K workspace; it is released at return, which is safe because the
+        # caching allocator only hands the block to later work on the same stream
+        scratch = torch.empty((total + ws_bytes,), dtype=torch.uint8, device=self.device)
+        base = scratch.data_ptr()
+        q = [base + o if sz else None for o, sz in zip(offs, sizes)]
+        out = torch.empty((m, self.n), dtype=torch.bfloat16, device=self.device)
+        stream = torch.cuda.current_stream().cuda_stream
+        idx, bn, bs, bo, sfbn, sfbs, sfbo = self.args
+        st = self.lib.mm_reorder_quantize(x2d.data_ptr(), m, self.k, idx, kn, ks, ko, 0, *q, stream)
+        if st == 0:
+            st = self.lib.mm_matmul_ws(q[0], bn, q[1], bs, q[2], bo, q[3], sfbn, q[4], sfbs, q[5], sfbo, m, self.n, kn, ks, ko,
+                                       self.wmode, 0, bias.data_ptr() if bias is not None else None, out.data_ptr(),
+                                       base + total if ws_bytes else None, ws_bytes, stream)
+        if st:
+            from . import _lib
+            _lib.check(st, "QLinearLayer.forward")
+        return out
+
+
 def _forward(layer, x):
     """shared by QLinearLayer and FusedQLinear: x tensor or pre-quantized tuple -> [M, N] bf16, bsz, q_len"""
     bias = layer.bias
@@ -67,17 +104,19 @@ def _forward(layer, x):
     else:
         bsz, q_len, k = x.shape
         m = bsz * q_len
-        if _DECODE_FUSED and 0 < m <= 8:
-            plan = layer.__dict__.get("_decode_plan")
-            if plan is None or plan.device != layer.BN.device:
-                plan = layer.__dict__["_decode_plan"] = _DecodePlan(layer)
-            if plan.wins(m):
-                if x.dtype is not torch.bfloat16 or x.device != plan.device or k != plan.k:
-                    raise TypeError(f"input must be a bfloat16 tensor [bsz, q_len, {plan.k}] on {plan.device}")
-                if bias is not None and bias.device != x.device:
-                    bias = bias.to(x.device)
-                return plan.run(x.reshape(m, k).contiguous(), bias), bsz, q_len
-        AN, AS, AO, SFAN, SFAS, SFAO, bsz, q_len = layer.quantize_input(x)
+        plan = layer.__dict__.get("_decode_plan")
+        if plan is None or plan.device != layer.BN.device:
+            plan = layer.__dict__["_decode_plan"] = _DecodePlan(layer)
+        if x.dtype is not torch.bfloat16 or x.device != plan.device or k != plan.k:
+            raise TypeError(f"input must be a bfloat16 tensor [bsz, q_len, {plan.k}] on {plan.device}")
+        if bias is not None and bias.device != x.device:
+            bias = bias.to(x.device)
+        x2d = x.reshape(m, k).contiguous()
+        if m == 0:
+            return torch.empty((0, plan.n), dtype=torch.bfloat16, device=plan.device), bsz, q_len
+        if _DECODE_FUSED and m <= 8 and plan.wins(m):
+            return plan.run(x2d, bias), bsz, q_len
+        return plan.run_two_op(x2d, bias), bsz, q_len
     if bias is not None and bias.device != AN.device:
         bias = bias.to(AN.device)
     y = mixedgemm.matmul(AN, layer.BN, AS, layer.BS, AO, layer.BO, SFAN, layer.SFBN, SFAS, layer.SFBS, SFAO, layer.SFBO,
