@@ -168,7 +168,8 @@ class QLinearLayer(nn.Module):
     @torch.no_grad()
     def forward(self, x):
         y, bsz, q_len = _forward(self, x)
-        return y.reshape(bsz, q_len, -1)
+        # the Mixtral expert caller passes bsz = None with 2-D token batches (qMixtralLayer.py:507-519)
+        return y.reshape(bsz, q_len, -1) if bsz is not None else y.reshape(q_len, -1)
 
 
 class FusedQLinear(nn.Module):
@@ -211,4 +212,6 @@ class FusedQLinear(nn.Module):
     @torch.no_grad()
     def forward(self, x):
         y, bsz, q_len = _forward(self, x)
+        if bsz is None:
+            return tuple(t.reshape(q_len, -1) for t in y.split(self.splits, dim=1))
         return tuple(t.reshape(bsz, q_len, -1) for t in y.split(self.splits, dim=1))

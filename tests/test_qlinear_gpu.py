@@ -79,3 +79,18 @@ def test_fused_layers_equal_separate_layers(dev, m):
             # the fused bias vector holds zeros for this layer: y = bf16(bf16(acc) + 0) = the same value
             pass
         assert torch.equal(y, ref)
+
+
+def test_expert_style_tuple_with_bsz_none(dev):
+    """qMixtralLayer.py:507-519: experts quantize a 2-D token batch themselves and pass (…, None, q_len)"""
+    import torch
+    from micromix_amd import mixedgemm
+    g = torch.Generator().manual_seed(9)
+    k, split = 512, (256, 128, 128)
+    idx = torch.randperm(k, generator=g)
+    layer = QLinearLayer(torch.nn.Linear(k, 256, bias=False, dtype=torch.bfloat16).to(dev), p8_num=split[2], p6_num=split[1],
+                         reorder_index=idx)
+    x = torch.randn((37, k), generator=g).to(torch.bfloat16).to(dev)
+    q = mixedgemm.reorder_quantize_x(x, layer.reorder_index, *split)
+    y = layer((*q, None, 37))
+    assert y.shape == (37, 256) and torch.equal(y, layer(x.unsqueeze(0))[0])
