@@ -96,3 +96,25 @@ def test_dropin_module_importable_by_path():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.matmul is mixedgemm.matmul and mod.reorder_quantize_w4 is mixedgemm.reorder_quantize_w4
+
+
+def test_new_entry_points_validate_on_the_host():
+    """split-K planning, the decode-kernel predicate and the rmsnorm entry are pure host logic until they launch."""
+    lib = _lib.load()
+    z = None
+    # no split for decode sizes, for the headline shape, or for bad splits; a split (and a positive size) for a medium-M shape
+    assert lib.mm_matmul_workspace_bytes(16, 4096, 0, 0, 4096, 1, 0) == 0
+    assert lib.mm_matmul_workspace_bytes(4096, 4096, 0, 0, 4096, 1, 0) == 0
+    assert lib.mm_matmul_workspace_bytes(128, 4096, 0, 0, 100, 1, 0) == 0
+    ws = lib.mm_matmul_workspace_bytes(128, 4096, 0, 0, 4096, 1, 0)
+    assert ws > 0 and ws % (128 * 1024) == 0                       # whole 128 KiB partial-sum blocks
+    assert lib.mm_matmul_workspace_bytes(128, 4096, 0, 0, 4096, 1, _lib.MM_SPLIT_K_ALWAYS) >= ws
+    assert lib.mm_qlinear_decode_supported(1, 4096, 2048, 128, 1920) == 2
+    assert lib.mm_qlinear_decode_supported(9, 4096, 2048, 128, 1920) == 0
+    assert lib.mm_qlinear_decode_supported(4, 4096, 100, 0, 0) == 0
+    assert lib.mm_qlinear_decode(z, z, z, z, z, z, z, z, 9, 128, 128, 0, 0, 1, 0, z, z, z) == _lib.MM_ERR_BAD_ARG or \
+        lib.mm_qlinear_decode(z, z, z, z, z, z, z, z, 9, 128, 128, 0, 0, 1, 0, z, z, z) == _lib.MM_ERR_UNSUPPORTED
+    assert lib.mm_qlinear_decode(z, z, z, z, z, z, z, z, 1, 128, 100, 0, 0, 1, 0, z, z, z) == _lib.MM_ERR_BAD_SPLIT
+    assert lib.mm_rmsnorm_quantize(z, z, 1e-5, 4, 256, z, 128, 64, 64, 0, z, z, z, z, z, z, z) == _lib.MM_ERR_BAD_SPLIT
+    assert lib.mm_rmsnorm_quantize(z, z, 1e-5, 0, 256, z, 128, 128, 0, 0, z, z, z, z, z, z, z) == _lib.MM_OK      # no rows
+    assert lib.mm_rmsnorm_quantize(z, z, 1e-5, 4, 256, z, 128, 128, 0, 0, z, z, z, z, z, z, z) == _lib.MM_ERR_BAD_ARG
