@@ -11,6 +11,14 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # Test-infrastructure convenience only: the product never builds or falls back by itself (micromix_amd._lib.load() raises
+    # when the library is absent).  If the built library did not travel with the checkout, build it once here.
+    from micromix_amd import _lib, build
+    if not os.path.exists(_lib.LIB_PATH):
+        try:
+            build.build(verbose=False)
+        except Exception as e:  # the tests that need the library will fail with the loader's message
+            print(f"[conftest] could not build libmicromix_hip.so: {e}", file=sys.stderr)
 
 
 def has_gpu() -> bool:
