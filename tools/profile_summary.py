@@ -12,13 +12,14 @@ for f in glob.glob(out + "/trace/*/*_kernel_stats.csv"):
     lines.append("== rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 200 --warmup 50 ==")
     for r in rows:
         lines.append(f"{r['Name'][:70]:70s} calls {r['Calls']:>5s} avg {float(r['AverageNs'])/1e3:8.2f} us min {float(r['MinNs'])/1e3:8.2f} max {float(r['MaxNs'])/1e3:8.2f} {float(r['Percentage']):6.2f}%")
-# the bench's two passes inside the same trace (W = 50, K = 200): launches 51..250 of the w4 GEMM kernel are the timed region
-# (`value`), launches 251..450 the pass with events attached to the dispatch (`roofline.kernel_us`)
+# bench.py's launches of the w4 GEMM kernel inside the same trace (W = 50, K = 200): 50 warm-up launches, 1 launch that warms the
+# capture stream, 200 of the untimed first graph replay, then launches 252..451 = the timed region (`value`, one hipGraph) and
+# launches 452..651 = the pass with events attached to each dispatch (`roofline.kernel_us`)
 for f in glob.glob(out + "/trace/*/*_kernel_trace.csv"):
     d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in csv.DictReader(open(f))
          if "mx_gemm256_kernel<true, false>" in r["Kernel_Name"]]
-    if len(d) >= 450:
-        for name, t in (("timed region (GEMM launches 51..250)", d[50:250]), ("event pass (GEMM launches 251..450)", d[250:450])):
+    if len(d) >= 651:
+        for name, t in (("timed region (GEMM launches 252..451, hipGraph)", d[251:451]), ("event pass (GEMM launches 452..651)", d[451:651])):
             lines.append(f"{name}: kernel-trace avg {sum(t)/len(t):.2f} us min {min(t):.2f} max {max(t):.2f}")
 bench_line = [l for l in open(out + "/bench_under_rocprof.log") if l.startswith("{")]
 if bench_line:
