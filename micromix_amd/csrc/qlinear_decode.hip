@@ -136,24 +136,31 @@ __global__ void __launch_bounds__(NT) qlinear_decode_kernel(Args a) {
 
     // ---- phase 1: quantize the M activation rows into LDS (reorder.cu:94-269 per group, shared quantize_group) ----
     // stage_rows rows are staged at a time and their (row, group) pairs are spread over all 512 threads
+    auto load_ix = [&](int g, uint32_t (&ix)[16]) {
+        const uint4 *p = reinterpret_cast<const uint4 *>(a.idx + (size_t)g * 32);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint4 q = p[i];
+            ix[4 * i] = (q.x << 1) & 0xFFFEFFFEu;      // byte offsets into the staged row, two per register
+            ix[4 * i + 1] = (q.y << 1) & 0xFFFEFFFEu;
+            ix[4 * i + 2] = (q.z << 1) & 0xFFFEFFFEu;
+            ix[4 * i + 3] = (q.w << 1) & 0xFFFEFFFEu;
+        }
+    };
     for (int r0 = 0; r0 < a.M; r0 += a.stage_rows) {
         const int nr = (a.M - r0) < a.stage_rows ? (a.M - r0) : a.stage_rows;
+        // the indices of this thread's first (row, group) pair are requested BEFORE the rows are staged, so the two global
+        // round trips overlap
+        uint32_t ix[16];
+        const int t0 = threadIdx.x;
+        if (t0 < nr * Gt) load_ix(t0 % Gt, ix);
         const uint4 *grow = reinterpret_cast<const uint4 *>(a.X + (size_t)r0 * Kt);
         for (int c = threadIdx.x; c < nr * (Kt >> 3); c += NT) reinterpret_cast<uint4 *>(stage)[c] = grow[c];
         __syncthreads();
-        for (int t = threadIdx.x; t < nr * Gt; t += NT) {
+        for (int t = t0; t < nr * Gt; t += NT) {
             const int rr = t / Gt, g = t - rr * Gt, r = r0 + rr;
             const uint8_t *row = stage + (size_t)rr * Kt * 2;
-            uint32_t ix[16];
-            const uint4 *p = reinterpret_cast<const uint4 *>(a.idx + (size_t)g * 32);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const uint4 q = p[i];
-                ix[4 * i] = (q.x << 1) & 0xFFFEFFFEu;
-                ix[4 * i + 1] = (q.y << 1) & 0xFFFEFFFEu;
-                ix[4 * i + 2] = (q.z << 1) & 0xFFFEFFFEu;
-                ix[4 * i + 3] = (q.w << 1) & 0xFFFEFFFEu;
-            }
+            if (t != t0) load_ix(g, ix);
             uint32_t byte;
             if (g < gN) byte = quantize_group<EL_FP4>(row, ix, opN + r * pN + g * 16);
             else if (g < gN + gS) byte = quantize_group<EL_FP6>(row, ix, opS + r * pS + (g - gN) * 24);
