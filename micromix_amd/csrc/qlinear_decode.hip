@@ -123,10 +123,14 @@ __device__ __forceinline__ void run_segment(v16f &acc, const uint8_t *xl, int xp
     }
 }
 
-template <bool W4>
-__global__ void __launch_bounds__(NT) qlinear_decode_kernel(Args a) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];   // [row stage | opN | opS | opO | scales]
-    __shared__ float red[NW][16][64];
+// LDS map of both kernels: [staged bf16 rows | opN | opS | opO | scale bytes]
+struct LdsMap {
+    uint8_t *opN, *opS, *opO, *scales;
+    int pN, pS, pO, Gt, gN, gS;
+};
+
+// phase 1: quantize the M activation rows into LDS (reorder.cu:94-269 per group, shared quantize_group)
+__device__ __forceinline__ LdsMap quantize_rows_to_lds(const Args &a, uint8_t *smem) {
     const int Kt = a.K[0] + a.K[1] + a.K[2], Gt = Kt >> 5;
     const int gN = a.K[0] >> 5, gS = a.K[1] >> 5;
     const int pN = a.K[0] >> 1, pS = (a.K[1] >> 2) * 3, pO = a.K[2];      // packed bytes per row and segment
@@ -169,6 +173,20 @@ __global__ void __launch_bounds__(NT) qlinear_decode_kernel(Args a) {
         }
         __syncthreads();
     }
+
+    LdsMap m;
+    m.opN = opN; m.opS = opS; m.opO = opO; m.scales = scales;
+    m.pN = pN; m.pS = pS; m.pO = pO; m.Gt = Gt; m.gN = gN; m.gS = gS;
+    return m;
+}
+
+template <bool W4>
+__global__ void __launch_bounds__(NT) qlinear_decode_kernel(Args a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];   // [row stage | opN | opS | opO | scales]
+    __shared__ float red[NW][16][64];
+    const LdsMap L = quantize_rows_to_lds(a, smem);
+    const uint8_t *opN = L.opN, *opS = L.opS, *opO = L.opO, *scales = L.scales;
+    const int pN = L.pN, pS = L.pS, pO = L.pO, Gt = L.Gt, gN = L.gN, gS = L.gS;
 
     // ---- phase 2: weight-streaming GEMM, 32 features per workgroup, K split over the 8 waves (mx_gemm_skinny.hip) ----
     const int n0 = blockIdx.x * BN;
@@ -215,6 +233,127 @@ __global__ void __launch_bounds__(NT) qlinear_decode_kernel(Args a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// 16-feature variant (v_mfma_scale_f32_16x16x128_f8f6f4: one MFMA per 128-deep slab, tokens on 16 rows): twice the workgroups
+// for the same N.  Used while N/32 workgroups would leave half of the CUs idle (N <= 4096 on 256 CUs), where a workgroup's
+// weight stream is latency bound (~25 GB/s per CU): down_proj at M = 1 14.8 -> ~10 us.
+// Register layouts (tests/test_hw_gpu.py): lane l = (row/col l & 15, K block h = l >> 4); fp4/fp6 lanes hold the 32 elements of
+// block h, fp8 lanes hold K = 16h + [0,16) and 64 + 16h + [0,16); the scale byte of a lane belongs to block h.
+// ---------------------------------------------------------------------------------------------------------
+typedef float v4f __attribute__((ext_vector_type(4)));
+constexpr int BN16 = 16;
+
+template <int EL>
+__device__ __forceinline__ v8i load_wfrag16(__amdgpu_buffer_rsrc_t rsrc, int rowoff, int slab, int h) {
+    const int so = slab * G<EL>::BYTES;
+    v8i r = {0, 0, 0, 0, 0, 0, 0, 0};
+    if constexpr (EL == EL_FP8) {
+        const v4i lo = __builtin_amdgcn_raw_buffer_load_b128(rsrc, rowoff + h * 16, so, 0);
+        const v4i hi = __builtin_amdgcn_raw_buffer_load_b128(rsrc, rowoff + 64 + h * 16, so, 0);
+        r = v8i{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    } else if constexpr (EL == EL_FP4) {
+        const v4i v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, rowoff + h * 16, so, 0);
+        r = v8i{v[0], v[1], v[2], v[3], 0, 0, 0, 0};
+    } else {
+        const int o = rowoff + h * 24;
+        const v2i a = __builtin_amdgcn_raw_buffer_load_b64(rsrc, o, so, 0);
+        const v2i b = __builtin_amdgcn_raw_buffer_load_b64(rsrc, o + 8, so, 0);
+        const v2i c = __builtin_amdgcn_raw_buffer_load_b64(rsrc, o + 16, so, 0);
+        r = v8i{a[0], a[1], b[0], b[1], c[0], c[1], 0, 0};
+    }
+    return r;
+}
+
+template <int EL>
+__device__ __forceinline__ v8i lds_xfrag16(const uint8_t *p, int h) {
+    v8i r = {0, 0, 0, 0, 0, 0, 0, 0};
+    if constexpr (EL == EL_FP8) {
+        const uint4 lo = *reinterpret_cast<const uint4 *>(p + h * 16);
+        const uint4 hi = *reinterpret_cast<const uint4 *>(p + 64 + h * 16);
+        r = v8i{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
+    } else if constexpr (EL == EL_FP4) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(p + h * 16);
+        r = v8i{(int)v.x, (int)v.y, (int)v.z, (int)v.w, 0, 0, 0, 0};
+    } else {
+        const uint2 *q = reinterpret_cast<const uint2 *>(p + h * 24);
+        const uint2 a = q[0], b = q[1], c = q[2];
+        r = v8i{(int)a.x, (int)a.y, (int)b.x, (int)b.y, (int)c.x, (int)c.y, 0, 0};
+    }
+    return r;
+}
+
+template <int XEL, int WEL>
+__device__ __forceinline__ void run_segment16(v4f &acc, const uint8_t *xl, int xp, const uint8_t *sl, int sp, const uint8_t *W,
+                                              const uint8_t *SFW, int nslab, int M, int N, int n0, int sfw_tiles) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int li = lane & 15, h = lane >> 4;
+    const int wrb = nslab * G<WEL>::BYTES;
+    int wrows = N - n0;
+    wrows = wrows > BN16 ? BN16 : wrows;
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(W + (size_t)n0 * wrb, (unsigned)wrows * (unsigned)wrb);
+    const __amdgpu_buffer_rsrc_t rsw = make_rsrc(SFW, (unsigned)sfw_tiles * (unsigned)nslab * 512u);
+    const int n = n0 + li;
+    const int sfw_off = (n >> 7) * nslab * 512 + (n & 31) * 16 + ((n >> 5) & 3) * 4;
+    const bool valid = li < M;
+    const uint8_t *xrow = xl + (valid ? li : 0) * xp;
+    const uint8_t *srow = sl + (valid ? li : 0) * sp;
+    const int sh = 8 * h;
+    for (int s = wave; s < nslab; s += NW) {
+        const int sw = __builtin_amdgcn_raw_buffer_load_b32(rsw, sfw_off, s * 512, 0) >> sh;
+        const v8i wf = load_wfrag16<WEL>(rw, li * wrb, s, h);
+        int sx = 0;
+        v8i xf = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (valid) {
+            sx = (int)(*reinterpret_cast<const uint32_t *>(srow + 4 * s) >> sh);
+            xf = lds_xfrag16<XEL>(xrow + s * G<XEL>::BYTES, h);
+        }
+        acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(xf, wf, acc, ElemTraits<XEL>::HW, ElemTraits<WEL>::HW, 0, sx, 0, sw);
+    }
+}
+
+template <bool W4>
+__global__ void __launch_bounds__(NT) qlinear_decode16_kernel(Args a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    __shared__ float red[NW][4][64];
+    const LdsMap L = quantize_rows_to_lds(a, smem);
+    const int n0 = blockIdx.x * BN16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nseg[3] = {a.K[0] >> 7, a.K[1] >> 7, a.K[2] >> 7};
+    v4f accN = {0, 0, 0, 0}, accS = {0, 0, 0, 0}, accO = {0, 0, 0, 0};
+    if (nseg[0]) run_segment16<EL_FP4, EL_FP4>(accN, L.opN, L.pN, L.scales, L.Gt, a.W[0], a.SFW[0], nseg[0], a.M, a.N, n0, a.sfw_row_tiles);
+    if (nseg[1]) run_segment16<EL_FP6, (W4 ? EL_FP4 : EL_FP6)>(accS, L.opS, L.pS, L.scales + L.gN, L.Gt, a.W[1], a.SFW[1], nseg[1], a.M, a.N, n0, a.sfw_row_tiles);
+    if (nseg[2]) run_segment16<EL_FP8, (W4 ? EL_FP4 : EL_FP8)>(accO, L.opO, L.pO, L.scales + L.gN + L.gS, L.Gt, a.W[2], a.SFW[2], nseg[2], a.M, a.N, n0, a.sfw_row_tiles);
+
+    // cross-wave reduction per segment with the reference's rounding chain; threads 0..255 own one output element each
+    float run = 0.0f;
+    auto reduce = [&](const v4f &acc) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) red[wave][i][lane] = acc[i];
+        __syncthreads();
+        if (threadIdx.x < 256) {
+            float s = 0.0f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) s += (&red[w][0][0])[threadIdx.x];
+            s += run;
+            run = a.round_per_segment ? bf16_bits_to_f32(f32_to_bf16_bits(s)) : s;
+        }
+    };
+    if (nseg[0]) reduce(accN);
+    if (nseg[1]) reduce(accS);
+    if (nseg[2]) reduce(accO);
+    if (threadIdx.x < 256) {
+        const int l = threadIdx.x & 63, i = threadIdx.x >> 6;
+        const int m = 4 * (l >> 4) + i;            // D[4 * (lane >> 4) + register][lane & 15]
+        const int n = n0 + (l & 15);
+        if (m < a.M && n < a.N) {
+            uint32_t b = f32_to_bf16_bits(run);
+            if (a.bias != nullptr) b = f32_to_bf16_bits(bf16_bits_to_f32(b) + bf16_bits_to_f32(a.bias[n]));
+            a.D[(size_t)m * a.N + n] = (uint16_t)b;
+        }
+    }
+}
+
 }  // namespace decode
 
 // dynamic LDS: the quantized rows and scales of all M rows + as many staged bf16 rows as fit next to the 32 KB reduction buffer
@@ -224,19 +363,27 @@ static size_t decode_operand_bytes(int M, const int K[3]) {   // quantized rows 
     return (size_t)M * (K[0] / 2 + K[1] / 4 * 3 + K[2] + Kt / 32);
 }
 
-// 0: cannot run; 1: can run; 2: can run and is expected to beat quantize + GEMM.  Every workgroup repeats the quantization, in
-// ceil(M * K/32 / 512) passes of ~1.4 us, and N/32 workgroups take ceil(N/32 / CUs) rounds; measured on MI355X the fused
-// kernel wins while rounds * passes <= 2 (q/o up to M = 8, gate/up and down up to M = 2-4) and loses beyond.
-int qlinear_decode_supported(int M, int N, const int K[3]) {
-    const size_t Kt = (size_t)K[0] + K[1] + K[2];
-    if (M < 1 || M > 8 || Kt * 2 + decode_operand_bytes(M, K) > DECODE_LDS_MAX) return 0;   // at least one staged row must fit
+static int device_cus() {
     static int cus = 0;
     if (cus == 0) {
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
             cus = 256;
     }
-    const int rounds = ((N + decode::BN - 1) / decode::BN + cus - 1) / cus;
+    return cus;
+}
+
+// features per workgroup: 16 while 32 would leave half of the CUs without a workgroup
+static int decode_features(int N) { return 2 * ((N + 31) / 32) <= device_cus() ? 16 : 32; }
+
+// 0: cannot run; 1: can run; 2: can run and is expected to beat quantize + GEMM.  Every workgroup repeats the quantization, in
+// ceil(M * K/32 / 512) passes of ~1.4 us, and the workgroups take ceil(N/features / CUs) rounds; measured on MI355X the fused
+// kernel wins while rounds * passes <= 2 (q/o up to M = 8, gate/up and down up to M = 2-4) and loses beyond.
+int qlinear_decode_supported(int M, int N, const int K[3]) {
+    const size_t Kt = (size_t)K[0] + K[1] + K[2];
+    if (M < 1 || M > 8 || Kt * 2 + decode_operand_bytes(M, K) > DECODE_LDS_MAX) return 0;   // at least one staged row must fit
+    const int feat = decode_features(N), cus = device_cus();
+    const int rounds = ((N + feat - 1) / feat + cus - 1) / cus;
     const int passes = (int)((M * (Kt / 32) + decode::NT - 1) / decode::NT);
     return rounds * passes <= 2 ? 2 : 1;
 }
@@ -245,7 +392,6 @@ hipError_t launch_qlinear_decode(const void *X, const int16_t *idx, const uint8_
                                  int M, int N, const int K[3], bool w4, int round_per_segment, const void *bias, void *D,
                                  hipStream_t stream) {
     using namespace decode;
-    static bool done[2] = {false, false};
     Args a;
     a.X = (const uint16_t *)X;
     a.idx = idx;
@@ -265,13 +411,18 @@ hipError_t launch_qlinear_decode(const void *X, const int16_t *idx, const uint8_
     stage_rows = stage_rows > M ? M : stage_rows;
     a.stage_rows = stage_rows;
     const size_t lds = (size_t)stage_rows * Kt * 2 + ops;
-    auto kern = w4 ? qlinear_decode_kernel<true> : qlinear_decode_kernel<false>;
-    if (!done[w4 ? 0 : 1]) {
+    const bool f16 = decode_features(N) == 16;
+    auto kern = f16 ? (w4 ? qlinear_decode16_kernel<true> : qlinear_decode16_kernel<false>)
+                    : (w4 ? qlinear_decode_kernel<true> : qlinear_decode_kernel<false>);
+    static bool done[4] = {false, false, false, false};
+    bool &d = done[(f16 ? 2 : 0) + (w4 ? 0 : 1)];
+    if (!d) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DECODE_LDS_MAX);
         if (e != hipSuccess) return e;
-        done[w4 ? 0 : 1] = true;
+        d = true;
     }
-    hipLaunchKernelGGL(kern, dim3((N + BN - 1) / BN), dim3(NT), lds, stream, a);
+    const int feat = f16 ? BN16 : BN;
+    hipLaunchKernelGGL(kern, dim3((N + feat - 1) / feat), dim3(NT), lds, stream, a);
     return hipGetLastError();
 }
 
