@@ -164,12 +164,121 @@ __global__ void __launch_bounds__(NT) mx_gemm_skinny_kernel(GemmArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// 16-feature variant for M <= 16 (v_mfma_scale_f32_16x16x128_f8f6f4, one MFMA per slab): twice the workgroups for the same N.
+// Used while N/32 workgroups would leave half of the CUs idle: a workgroup's weight stream is latency bound (~25 GB/s per CU),
+// so for N <= 4096 the extra workgroups nearly halve the time of the long-K layers (down_proj).
+// Register layouts (tests/test_hw_gpu.py): lane l = (row/col l & 15, K block h = l >> 4); fp4/fp6 lanes hold the 32 elements of
+// block h, fp8 lanes hold K = 16h + [0,16) and 64 + 16h + [0,16); the scale byte of a lane belongs to block h.
+// ---------------------------------------------------------------------------------------------------------
+typedef float v4f __attribute__((ext_vector_type(4)));
+constexpr int BN16 = 16;
+
+template <int EL>
+__device__ __forceinline__ v8i load_frag16(__amdgpu_buffer_rsrc_t rsrc, int rowoff, int slab, int h) {
+    const int so = slab * G<EL>::BYTES;
+    v8i r = {0, 0, 0, 0, 0, 0, 0, 0};
+    if constexpr (EL == EL_FP8) {
+        const v4i lo = __builtin_amdgcn_raw_buffer_load_b128(rsrc, rowoff + h * 16, so, 0);
+        const v4i hi = __builtin_amdgcn_raw_buffer_load_b128(rsrc, rowoff + 64 + h * 16, so, 0);
+        r = v8i{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    } else if constexpr (EL == EL_FP4) {
+        const v4i v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, rowoff + h * 16, so, 0);
+        r = v8i{v[0], v[1], v[2], v[3], 0, 0, 0, 0};
+    } else {
+        typedef int v2i __attribute__((ext_vector_type(2)));
+        const int o = rowoff + h * 24;
+        const v2i a = __builtin_amdgcn_raw_buffer_load_b64(rsrc, o, so, 0);
+        const v2i b = __builtin_amdgcn_raw_buffer_load_b64(rsrc, o + 8, so, 0);
+        const v2i c = __builtin_amdgcn_raw_buffer_load_b64(rsrc, o + 16, so, 0);
+        r = v8i{a[0], a[1], b[0], b[1], c[0], c[1], 0, 0};
+    }
+    return r;
+}
+
+template <int XEL, int WEL>
+__device__ __forceinline__ void run_segment16(v4f &acc, const uint8_t *X, const uint8_t *W, const uint8_t *SFX, const uint8_t *SFW,
+                                              int nslab, int M, int N, int n0, int sfx_tiles, int sfw_tiles) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int li = lane & 15, h = lane >> 4;
+    const int xrb = nslab * G<XEL>::BYTES, wrb = nslab * G<WEL>::BYTES;
+    int wrows = N - n0;
+    wrows = wrows > BN16 ? BN16 : wrows;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(X, (unsigned)M * (unsigned)xrb);
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(W + (size_t)n0 * wrb, (unsigned)wrows * (unsigned)wrb);
+    const __amdgpu_buffer_rsrc_t rsx = make_rsrc(SFX, (unsigned)sfx_tiles * (unsigned)nslab * 512u);
+    const __amdgpu_buffer_rsrc_t rsw = make_rsrc(SFW, (unsigned)sfw_tiles * (unsigned)nslab * 512u);
+    const int n = n0 + li;
+    const int sfw_off = (n >> 7) * nslab * 512 + (n & 31) * 16 + ((n >> 5) & 3) * 4;
+    const int sfx_off = li * 16;   // token rows 0..15: row group 0 of atom row-tile 0
+    const int sh = 8 * h;
+#pragma unroll 2
+    for (int s = wave; s < nslab; s += NW) {
+        const int sw = __builtin_amdgcn_raw_buffer_load_b32(rsw, sfw_off, s * 512, 0) >> sh;
+        const int sx = __builtin_amdgcn_raw_buffer_load_b32(rsx, sfx_off, s * 512, 0) >> sh;
+        const v8i wf = load_frag16<WEL>(rw, li * wrb, s, h);
+        const v8i xf = load_frag16<XEL>(rx, li * xrb, s, h);
+        acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(xf, wf, acc, ElemTraits<XEL>::HW, ElemTraits<WEL>::HW, 0, sx, 0, sw);
+    }
+}
+
+template <bool W4>
+__global__ void __launch_bounds__(NT) mx_gemm_skinny16_kernel(GemmArgs a) {
+    __shared__ float red[NW][4][64];
+    const int n0 = blockIdx.x * BN16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nseg[3] = {a.K[0] >> 7, a.K[1] >> 7, a.K[2] >> 7};
+    v4f accN = {0, 0, 0, 0}, accS = {0, 0, 0, 0}, accO = {0, 0, 0, 0};
+    if (nseg[0]) run_segment16<EL_FP4, EL_FP4>(accN, a.X[0], a.W[0], a.SFX[0], a.SFW[0], nseg[0], a.M, a.N, n0, a.sfx_row_tiles, a.sfw_row_tiles);
+    if (nseg[1]) run_segment16<EL_FP6, (W4 ? EL_FP4 : EL_FP6)>(accS, a.X[1], a.W[1], a.SFX[1], a.SFW[1], nseg[1], a.M, a.N, n0, a.sfx_row_tiles, a.sfw_row_tiles);
+    if (nseg[2]) run_segment16<EL_FP8, (W4 ? EL_FP4 : EL_FP8)>(accO, a.X[2], a.W[2], a.SFX[2], a.SFW[2], nseg[2], a.M, a.N, n0, a.sfx_row_tiles, a.sfw_row_tiles);
+
+    // cross-wave reduction per segment with the reference's rounding chain; threads 0..255 own one output element each
+    float run = 0.0f;
+    auto reduce = [&](const v4f &acc) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) red[wave][i][lane] = acc[i];
+        __syncthreads();
+        if (threadIdx.x < 256) {
+            float s = 0.0f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) s += (&red[w][0][0])[threadIdx.x];
+            s += run;
+            run = a.round_per_segment ? bf16_bits_to_f32(f32_to_bf16_bits(s)) : s;
+        }
+    };
+    if (nseg[0]) reduce(accN);
+    if (nseg[1]) reduce(accS);
+    if (nseg[2]) reduce(accO);
+    if (threadIdx.x < 256) {
+        const int l = threadIdx.x & 63, i = threadIdx.x >> 6;
+        const int m = 4 * (l >> 4) + i;            // D[4 * (lane >> 4) + register][lane & 15]
+        const int n = n0 + (l & 15);
+        if (m < a.M && n < a.N) {
+            uint32_t b = f32_to_bf16_bits(run);
+            if (a.bias != nullptr) b = f32_to_bf16_bits(bf16_bits_to_f32(b) + bf16_bits_to_f32(a.bias[n]));
+            a.D[(size_t)m * a.N + n] = (uint16_t)b;
+        }
+    }
+}
+
 }  // namespace skinny
 
 hipError_t launch_mx_gemm_skinny(const GemmArgs &a, bool w4, hipStream_t stream) {
     using namespace skinny;
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = 256;
+    }
     const int blocks = (a.N + BN - 1) / BN;
-    if (a.M <= 32) {
+    if (a.M <= 16 && 2 * blocks <= cus) {   // 16 features per workgroup while 32 would leave half of the CUs idle
+        const int b16 = (a.N + BN16 - 1) / BN16;
+        if (w4) hipLaunchKernelGGL((mx_gemm_skinny16_kernel<true>), dim3(b16), dim3(NT), 0, stream, a);
+        else hipLaunchKernelGGL((mx_gemm_skinny16_kernel<false>), dim3(b16), dim3(NT), 0, stream, a);
+    } else if (a.M <= 32) {
         if (w4) hipLaunchKernelGGL((mx_gemm_skinny_kernel<true, 1>), dim3(blocks), dim3(NT), 0, stream, a);
         else hipLaunchKernelGGL((mx_gemm_skinny_kernel<false, 1>), dim3(blocks), dim3(NT), 0, stream, a);
     } else {

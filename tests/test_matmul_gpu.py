@@ -43,6 +43,8 @@ SHAPES = [
     (130, 256, 4096, (2048, 1024, 1024)), (257, 512, 1024, (0, 0, 1024)), (64, 200, 512, (256, 0, 256)),
     (300, 1024, 2048, (1024, 0, 1024)), (96, 640, 5120, (4096, 512, 512)),
     (140, 131, 256, (128, 0, 128)), (300, 72, 128, (0, 128, 0)), (513, 257, 384, (128, 128, 128)),   # odd N: scalar store path
+    (16, 200, 640, (256, 128, 256)), (12, 4096, 384, (128, 128, 128)),    # M <= 16: 16-feature skinny kernel (N <= 4096)
+    (9, 4128, 256, (128, 0, 128)), (20, 384, 640, (256, 128, 256)),       # 32-feature skinny kernel, one token tile
 ]
 # shapes the library runs as split-K when given a workspace (few output tiles, M > 64); each also runs unsplit
 SPLIT_SHAPES = [
