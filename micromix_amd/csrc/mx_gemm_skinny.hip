@@ -12,6 +12,8 @@
 //  * each wave keeps ONE accumulator set PER SEGMENT (16 registers per 32 tokens), the eight partial sums of a segment
 //    meet in LDS, and the chain D = bf16(N); D = bf16(S + D); D = bf16(O + D) is applied on the reduced values, so the
 //    reference's rounding order is reproduced exactly although K is split across waves.
+#include <stdlib.h>
+
 #include "mx_common.h"
 #include "mx_kernels.h"
 
@@ -274,7 +276,8 @@ hipError_t launch_mx_gemm_skinny(const GemmArgs &a, bool w4, hipStream_t stream)
             cus = 256;
     }
     const int blocks = (a.N + BN - 1) / BN;
-    if (a.M <= 16 && 2 * blocks <= cus) {   // 16 features per workgroup while 32 would leave half of the CUs idle
+    static const int force16 = getenv("MICROMIX_SKINNY16") ? atoi(getenv("MICROMIX_SKINNY16")) : 0;   // kernel-developer override
+    if (a.M <= 16 && (2 * blocks <= cus || force16)) {   // 16 features per workgroup while 32 would leave half of the CUs idle
         const int b16 = (a.N + BN16 - 1) / BN16;
         if (w4) hipLaunchKernelGGL((mx_gemm_skinny16_kernel<true>), dim3(b16), dim3(NT), 0, stream, a);
         else hipLaunchKernelGGL((mx_gemm_skinny16_kernel<false>), dim3(b16), dim3(NT), 0, stream, a);
