@@ -167,7 +167,7 @@ __global__ void __launch_bounds__(NT) mx_gemm_skinny_kernel(GemmArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// 16-feature variant for M <= 16 (v_mfma_scale_f32_16x16x128_f8f6f4, one MFMA per slab): twice the workgroups for the same N.
+// 16-feature variant (v_mfma_scale_f32_16x16x128_f8f6f4, one MFMA per slab and 16-token tile): twice the workgroups for the same N.
 // Used while N/32 workgroups would leave half of the CUs idle: a workgroup's weight stream is latency bound (~25 GB/s per CU),
 // so for N <= 4096 the extra workgroups nearly halve the time of the long-K layers (down_proj).
 // Register layouts (tests/test_hw_gpu.py): lane l = (row/col l & 15, K block h = l >> 4); fp4/fp6 lanes hold the 32 elements of
@@ -198,9 +198,10 @@ __device__ __forceinline__ v8i load_frag16(__amdgpu_buffer_rsrc_t rsrc, int rowo
     return r;
 }
 
-template <int XEL, int WEL>
-__device__ __forceinline__ void run_segment16(v4f &acc, const uint8_t *X, const uint8_t *W, const uint8_t *SFX, const uint8_t *SFW,
-                                              int nslab, int M, int N, int n0, int sfx_tiles, int sfw_tiles) {
+// T16 token tiles of 16 rows each (M <= 16 * T16)
+template <int XEL, int WEL, int T16>
+__device__ __forceinline__ void run_segment16(v4f (&acc)[T16], const uint8_t *X, const uint8_t *W, const uint8_t *SFX,
+                                              const uint8_t *SFW, int nslab, int M, int N, int n0, int sfx_tiles, int sfw_tiles) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int li = lane & 15, h = lane >> 4;
     const int xrb = nslab * G<XEL>::BYTES, wrb = nslab * G<WEL>::BYTES;
@@ -212,42 +213,62 @@ __device__ __forceinline__ void run_segment16(v4f &acc, const uint8_t *X, const 
     const __amdgpu_buffer_rsrc_t rsw = make_rsrc(SFW, (unsigned)sfw_tiles * (unsigned)nslab * 512u);
     const int n = n0 + li;
     const int sfw_off = (n >> 7) * nslab * 512 + (n & 31) * 16 + ((n >> 5) & 3) * 4;
-    const int sfx_off = li * 16;   // token rows 0..15: row group 0 of atom row-tile 0
+    int sfx_off[T16];
+#pragma unroll
+    for (int t = 0; t < T16; ++t) sfx_off[t] = ((t & 1) * 16 + li) * 16 + (t >> 1) * 4;   // token row 16t + li < 64: atom row-tile 0
     const int sh = 8 * h;
 #pragma unroll 2
     for (int s = wave; s < nslab; s += NW) {
         const int sw = __builtin_amdgcn_raw_buffer_load_b32(rsw, sfw_off, s * 512, 0) >> sh;
-        const int sx = __builtin_amdgcn_raw_buffer_load_b32(rsx, sfx_off, s * 512, 0) >> sh;
         const v8i wf = load_frag16<WEL>(rw, li * wrb, s, h);
-        const v8i xf = load_frag16<XEL>(rx, li * xrb, s, h);
-        acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(xf, wf, acc, ElemTraits<XEL>::HW, ElemTraits<WEL>::HW, 0, sx, 0, sw);
+        int sx[T16];
+        v8i xf[T16];
+#pragma unroll
+        for (int t = 0; t < T16; ++t) {
+            sx[t] = __builtin_amdgcn_raw_buffer_load_b32(rsx, sfx_off[t], s * 512, 0) >> sh;
+            xf[t] = load_frag16<XEL>(rx, (t * 16 + li) * xrb, s, h);
+        }
+#pragma unroll
+        for (int t = 0; t < T16; ++t)
+            acc[t] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(xf[t], wf, acc[t], ElemTraits<XEL>::HW, ElemTraits<WEL>::HW, 0,
+                                                                     sx[t], 0, sw);
     }
 }
 
-template <bool W4>
+template <bool W4, int T16>
 __global__ void __launch_bounds__(NT) mx_gemm_skinny16_kernel(GemmArgs a) {
-    __shared__ float red[NW][4][64];
+    __shared__ float red[NW][T16 * 4][64];
     const int n0 = blockIdx.x * BN16;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nseg[3] = {a.K[0] >> 7, a.K[1] >> 7, a.K[2] >> 7};
-    v4f accN = {0, 0, 0, 0}, accS = {0, 0, 0, 0}, accO = {0, 0, 0, 0};
-    if (nseg[0]) run_segment16<EL_FP4, EL_FP4>(accN, a.X[0], a.W[0], a.SFX[0], a.SFW[0], nseg[0], a.M, a.N, n0, a.sfx_row_tiles, a.sfw_row_tiles);
-    if (nseg[1]) run_segment16<EL_FP6, (W4 ? EL_FP4 : EL_FP6)>(accS, a.X[1], a.W[1], a.SFX[1], a.SFW[1], nseg[1], a.M, a.N, n0, a.sfx_row_tiles, a.sfw_row_tiles);
-    if (nseg[2]) run_segment16<EL_FP8, (W4 ? EL_FP4 : EL_FP8)>(accO, a.X[2], a.W[2], a.SFX[2], a.SFW[2], nseg[2], a.M, a.N, n0, a.sfx_row_tiles, a.sfw_row_tiles);
+    v4f accN[T16], accS[T16], accO[T16];
+#pragma unroll
+    for (int t = 0; t < T16; ++t) accN[t] = accS[t] = accO[t] = v4f{0, 0, 0, 0};
+    if (nseg[0]) run_segment16<EL_FP4, EL_FP4, T16>(accN, a.X[0], a.W[0], a.SFX[0], a.SFW[0], nseg[0], a.M, a.N, n0, a.sfx_row_tiles, a.sfw_row_tiles);
+    if (nseg[1]) run_segment16<EL_FP6, (W4 ? EL_FP4 : EL_FP6), T16>(accS, a.X[1], a.W[1], a.SFX[1], a.SFW[1], nseg[1], a.M, a.N, n0, a.sfx_row_tiles, a.sfw_row_tiles);
+    if (nseg[2]) run_segment16<EL_FP8, (W4 ? EL_FP4 : EL_FP8), T16>(accO, a.X[2], a.W[2], a.SFX[2], a.SFW[2], nseg[2], a.M, a.N, n0, a.sfx_row_tiles, a.sfw_row_tiles);
 
-    // cross-wave reduction per segment with the reference's rounding chain; threads 0..255 own one output element each
-    float run = 0.0f;
-    auto reduce = [&](const v4f &acc) {
+    // cross-wave reduction per segment with the reference's rounding chain; element e = (t, i, l) of the T16 x 4 x 64
+    // accumulator image: token 16t + 4 * (l >> 4) + i, feature n0 + (l & 15); threads 0..255 own elements e = tid + 256 j
+    float run[T16];
+#pragma unroll
+    for (int j = 0; j < T16; ++j) run[j] = 0.0f;
+    auto reduce = [&](const v4f (&acc)[T16]) {
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 4; ++i) red[wave][i][lane] = acc[i];
+        for (int t = 0; t < T16; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) red[wave][t * 4 + i][lane] = acc[t][i];
         __syncthreads();
         if (threadIdx.x < 256) {
-            float s = 0.0f;
 #pragma unroll
-            for (int w = 0; w < NW; ++w) s += (&red[w][0][0])[threadIdx.x];
-            s += run;
-            run = a.round_per_segment ? bf16_bits_to_f32(f32_to_bf16_bits(s)) : s;
+            for (int j = 0; j < T16; ++j) {
+                float s = 0.0f;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) s += (&red[w][0][0])[threadIdx.x + 256 * j];
+                s += run[j];
+                run[j] = a.round_per_segment ? bf16_bits_to_f32(f32_to_bf16_bits(s)) : s;
+            }
         }
     };
     if (nseg[0]) reduce(accN);
@@ -255,12 +276,15 @@ __global__ void __launch_bounds__(NT) mx_gemm_skinny16_kernel(GemmArgs a) {
     if (nseg[2]) reduce(accO);
     if (threadIdx.x < 256) {
         const int l = threadIdx.x & 63, i = threadIdx.x >> 6;
-        const int m = 4 * (l >> 4) + i;            // D[4 * (lane >> 4) + register][lane & 15]
         const int n = n0 + (l & 15);
-        if (m < a.M && n < a.N) {
-            uint32_t b = f32_to_bf16_bits(run);
-            if (a.bias != nullptr) b = f32_to_bf16_bits(bf16_bits_to_f32(b) + bf16_bits_to_f32(a.bias[n]));
-            a.D[(size_t)m * a.N + n] = (uint16_t)b;
+#pragma unroll
+        for (int j = 0; j < T16; ++j) {
+            const int m = 16 * j + 4 * (l >> 4) + i;            // D[4 * (lane >> 4) + register][lane & 15] per token tile
+            if (m < a.M && n < a.N) {
+                uint32_t b = f32_to_bf16_bits(run[j]);
+                if (a.bias != nullptr) b = f32_to_bf16_bits(bf16_bits_to_f32(b) + bf16_bits_to_f32(a.bias[n]));
+                a.D[(size_t)m * a.N + n] = (uint16_t)b;
+            }
         }
     }
 }
@@ -277,10 +301,18 @@ hipError_t launch_mx_gemm_skinny(const GemmArgs &a, bool w4, hipStream_t stream)
     }
     const int blocks = (a.N + BN - 1) / BN;
     static const int force16 = getenv("MICROMIX_SKINNY16") ? atoi(getenv("MICROMIX_SKINNY16")) : 0;   // kernel-developer override
-    if (a.M <= 16 && (2 * blocks <= cus || force16)) {   // 16 features per workgroup while 32 would leave half of the CUs idle
+    if (2 * blocks <= cus || (force16 && a.M <= 16)) {   // 16 features per workgroup while 32 would leave half of the CUs idle
         const int b16 = (a.N + BN16 - 1) / BN16;
-        if (w4) hipLaunchKernelGGL((mx_gemm_skinny16_kernel<true>), dim3(b16), dim3(NT), 0, stream, a);
-        else hipLaunchKernelGGL((mx_gemm_skinny16_kernel<false>), dim3(b16), dim3(NT), 0, stream, a);
+#define MM_L16(T_)                                                                                              \
+    do {                                                                                                        \
+        if (w4) hipLaunchKernelGGL((mx_gemm_skinny16_kernel<true, T_>), dim3(b16), dim3(NT), 0, stream, a);     \
+        else hipLaunchKernelGGL((mx_gemm_skinny16_kernel<false, T_>), dim3(b16), dim3(NT), 0, stream, a);       \
+    } while (0)
+        if (a.M <= 16) MM_L16(1);
+        else if (a.M <= 32) MM_L16(2);
+        else if (a.M <= 48) MM_L16(3);
+        else MM_L16(4);
+#undef MM_L16
     } else if (a.M <= 32) {
         if (w4) hipLaunchKernelGGL((mx_gemm_skinny_kernel<true, 1>), dim3(blocks), dim3(NT), 0, stream, a);
         else hipLaunchKernelGGL((mx_gemm_skinny_kernel<false, 1>), dim3(blocks), dim3(NT), 0, stream, a);
