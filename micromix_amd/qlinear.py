@@ -23,7 +23,7 @@ class _DecodePlan:
     mode), validated once.  `run` is the fused decode kernel (one torch.empty + one ctypes call, ~8 us of host time instead of
     ~20); `run_two_op` is reorder_quantize_x + matmul with ONE scratch allocation for the six quantizer outputs instead of six
     (~12 us instead of ~34), which is what bounds the eager throughput for 8 < M < ~512."""
-    __slots__ = ("lib", "args", "n", "k", "split", "wmode", "device", "index", "benefit", "ws_bytes")
+    __slots__ = ("lib", "args", "refs", "n", "k", "split", "wmode", "device", "index", "benefit", "ws_bytes")
 
     def __init__(self, layer):
         from . import _lib
@@ -35,10 +35,18 @@ class _DecodePlan:
         same = layer.BS.size(1) == layer.p6_num // 4 * 3 and layer.BO.size(1) == layer.p8_num
         self.wmode = _lib.MM_W_MATCH if same else _lib.MM_W_FP4
         ptr = lambda t: t.data_ptr() if t.numel() else None
+        # the tensors themselves are kept (alive, and compared by identity on every call: a layer whose packed weights were
+        # replaced gets a new plan instead of stale pointers)
+        self.refs = (layer.reorder_index, layer.BN, layer.BS, layer.BO, layer.SFBN, layer.SFBS, layer.SFBO)
         self.args = (ptr(layer.reorder_index), ptr(layer.BN), ptr(layer.BS), ptr(layer.BO), ptr(layer.SFBN), ptr(layer.SFBS),
                      ptr(layer.SFBO))
         self.benefit = {}          # rows -> mm_qlinear_decode_supported(...) == 2
         self.ws_bytes = {}         # rows -> mm_matmul_workspace_bytes(...)
+
+    def matches(self, layer):
+        r = self.refs
+        return (r[1] is layer.BN and r[0] is layer.reorder_index and r[2] is layer.BS and r[3] is layer.BO
+                and r[4] is layer.SFBN and r[5] is layer.SFBS and r[6] is layer.SFBO)
 
     def wins(self, m):
         w = self.benefit.get(m)
@@ -105,7 +113,7 @@ def _forward(layer, x):
         bsz, q_len, k = x.shape
         m = bsz * q_len
         plan = layer.__dict__.get("_decode_plan")
-        if plan is None or plan.device != layer.BN.device:
+        if plan is None or not plan.matches(layer):
             plan = layer.__dict__["_decode_plan"] = _DecodePlan(layer)
         if x.dtype is not torch.bfloat16 or x.device != plan.device or k != plan.k:
             raise TypeError(f"input must be a bfloat16 tensor [bsz, q_len, {plan.k}] on {plan.device}")

@@ -94,3 +94,22 @@ def test_expert_style_tuple_with_bsz_none(dev):
     q = mixedgemm.reorder_quantize_x(x, layer.reorder_index, *split)
     y = layer((*q, None, 37))
     assert y.shape == (37, 256) and torch.equal(y, layer(x.unsqueeze(0))[0])
+
+
+def test_call_plan_follows_replaced_weights(dev):
+    """the cached C-ABI call plan must not outlive the packed tensors it points at"""
+    import torch
+    g = torch.Generator().manual_seed(12)
+    k, split = 512, (256, 128, 128)
+    idx = torch.randperm(k, generator=g)
+    mk = lambda: QLinearLayer(torch.nn.Linear(k, 128, bias=False, dtype=torch.bfloat16).to(dev), p8_num=split[2], p6_num=split[1],
+                              reorder_index=idx)
+    a, b = mk(), mk()
+    x = torch.randn((1, 4, k), generator=g).to(torch.bfloat16).to(dev)
+    ya, yb = a(x), b(x)
+    assert not torch.equal(ya, yb)
+    for name in ("BN", "BS", "BO", "SFBN", "SFBS", "SFBO"):      # a takes b's weights
+        setattr(a, name, getattr(b, name))
+    assert torch.equal(a(x), yb)
+    x2 = torch.randn((1, 40, k), generator=g).to(torch.bfloat16).to(dev)
+    assert torch.equal(a(x2), b(x2))
