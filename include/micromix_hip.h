@@ -64,7 +64,7 @@ enum mm_matmul_flags {
                                  gain (tests and tuning) */
 };
 
-int mm_version(void);
+int mm_version(void); /* major * 10000 + minor * 100 + patch */
 const char *mm_strerror(int status);
 /* Text of the last HIP error seen by this thread ("" if none). */
 const char *mm_last_error(void);

@@ -23,7 +23,7 @@ static bool split_ok(int K, int KN, int KS, int KO) {
 
 extern "C" {
 
-int mm_version(void) { return 100; /* 0.1.0 */ }
+int mm_version(void) { return 130; /* 0.1.3: + mm_matmul_ws, mm_rmsnorm_quantize, mm_qlinear_decode */ }
 
 const char *mm_strerror(int status) {
     switch (status) {
