@@ -224,20 +224,22 @@ hipError_t launch_mx_gemm256(const GemmArgs &a, bool w4, hipStream_t stream) {
             return hipGetLastError();
         }
     }
-    // 256-row tiles move the fewest L2->LDS bytes per flop; use them when they (nearly) fill the 256 CUs, otherwise halve
-    // the tile height so that twice as many workgroups exist.
     static const int force = env_int("MICROMIX_GEMM_TILE", 0);   // kernel-developer override: 256 or 128
     static const int tail_split = env_int("MICROMIX_GEMM_TAIL", 1);
-    const bool use128 = force == 128 || (force != 256 && tiles256 < 192);
-    // Tail balancing: one workgroup per CU, so tiles256 = q * CUs + R runs q + 1 rounds and the last one leaves CUs idle.
-    // When R <= CUs / 2 and R is a whole number of tile columns, those columns are run as 128-row tiles instead (2R
-    // workgroups of half the work: the last round takes half the time).  gate/up at M = 4096: 896 tiles = 3.5 rounds.
     static int cus = 0;
     if (cus == 0) {
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
             cus = 256;
     }
+    // One workgroup fits per CU, so a launch runs in rounds of `cus` tiles.  256-row tiles move the fewest L2->LDS bytes per
+    // flop; a round of 128-row tiles takes ~0.62 of a round of 256-row tiles (measured).  So 128-row tiles pay exactly when
+    // they still fit in ONE round (tiles128 <= cus, i.e. at most half of the CUs would get a 256-row tile): M=2048, N=4096
+    // 46.5 -> 33 us; with 160 256-row tiles (320 128-row tiles = two rounds) the 256-row tiles win, 62 vs 76 us.
+    const bool use128 = force == 128 || (force != 256 && tiles128 <= cus);
+    // Tail balancing: tiles256 = q * CUs + R runs q + 1 rounds and the last one leaves CUs idle.
+    // When R <= CUs / 2 and R is a whole number of tile columns, those columns are run as 128-row tiles instead (2R
+    // workgroups of half the work: the last round takes half the time).  gate/up at M = 4096: 896 tiles = 3.5 rounds.
     const int tm256 = (a.M + 255) / 256, rem = tiles256 % cus;
     if (!use128 && tail_split && force == 0 && tiles256 > cus && rem > 0 && 2 * rem <= cus && rem % tm256 == 0) {
         const int c = rem / tm256;
