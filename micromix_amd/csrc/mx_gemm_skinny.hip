@@ -81,7 +81,6 @@ __device__ __forceinline__ void run_segment(v16f (&acc)[TM], const uint8_t *X, c
     for (int t = 0; t < TM; ++t) sfx_off[t] = li * 16 + t * 4;  // rows t*32 + li < 128: atom row-tile 0
     const int sh = 8 * kb;
 
-#pragma unroll 2
     for (int s = wave; s < nslab; s += NW) {
         const int sw = __builtin_amdgcn_raw_buffer_load_b32(rsw, sfw_off, s * 512, 0) >> sh;
         int sx[TM];
@@ -217,7 +216,6 @@ __device__ __forceinline__ void run_segment16(v4f (&acc)[T16], const uint8_t *X,
 #pragma unroll
     for (int t = 0; t < T16; ++t) sfx_off[t] = ((t & 1) * 16 + li) * 16 + (t >> 1) * 4;   // token row 16t + li < 64: atom row-tile 0
     const int sh = 8 * h;
-#pragma unroll 2
     for (int s = wave; s < nslab; s += NW) {
         const int sw = __builtin_amdgcn_raw_buffer_load_b32(rsw, sfw_off, s * 512, 0) >> sh;
         const v8i wf = load_frag16<WEL>(rw, li * wrb, s, h);
