@@ -118,10 +118,14 @@ rmsnorm_quantize_kernel(const uint16_t *__restrict__ src, const uint16_t *__rest
         }
         return sum;
     };
-    fetch(blockIdx.x);
+    // (the 1024-thread variant, K > 16384, has only 128 registers per lane: it fetches each row when it needs it instead
+    // of one row ahead)
+    constexpr bool PREFETCH = MAXT <= 512;
+    if constexpr (PREFETCH) fetch(blockIdx.x);
     for (int r = blockIdx.x; r < rows; r += gridDim.x) {
+        if constexpr (!PREFETCH) fetch(r);
         const float sum = stage_and_sum();
-        fetch(r + gridDim.x);
+        if constexpr (PREFETCH) fetch(r + gridDim.x);
         part[g] = sum;              // threads T.. contribute the zero padding (P < 2 * blockDim.x)
         if (g + (int)blockDim.x < P) part[g + blockDim.x] = 0.0f;
         __syncthreads();
@@ -170,7 +174,9 @@ hipError_t launch_rmsnorm_quantize(const void *src, const void *weight, float ep
     int P = 64;
     while (P < T) P <<= 1;
     const size_t lds = (size_t)K * 2 + (size_t)(P > threads ? P : threads) * 4;
+    // 256 / 512 / 1024 threads: K <= 8192 / 16384 / 32768 (the 1024-thread variant is limited to 128 registers and spills a few)
     auto kern = threads <= 256 ? (integer_round ? rmsnorm_quantize_kernel<true, 256> : rmsnorm_quantize_kernel<false, 256>)
+              : threads <= 512 ? (integer_round ? rmsnorm_quantize_kernel<true, 512> : rmsnorm_quantize_kernel<false, 512>)
                                : (integer_round ? rmsnorm_quantize_kernel<true, 1024> : rmsnorm_quantize_kernel<false, 1024>);
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kern), threads, lds) != hipSuccess ||
