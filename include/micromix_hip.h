@@ -156,6 +156,22 @@ int mm_matmul_ws(const uint8_t *AN, const uint8_t *BN, const uint8_t *AS, const 
                  const void *bias_bf16, void *D_bf16, void *workspace, size_t workspace_bytes, mm_stream_t stream);
 
 /*
+ * Grouped GEMM (MoE experts; reference caller: the per-expert loop of model/qMixtralLayer.py:507-519, one matmul per expert and
+ * linear): `ngroups` independent products D_g = matmul(A_g, B_g) that share N, the (KN, KS, KO) split, the weight mode and the
+ * flags but have their own operands, token counts and outputs.  Groups of at most 64 token rows share launches of the
+ * weight-streaming kernels, 8 groups per launch; larger groups run through mm_matmul one after the other.  Results are
+ * bit-identical to ngroups calls of mm_matmul.  `groups` is a HOST array (copied into the kernel arguments).
+ */
+typedef struct mm_group {
+    const uint8_t *AN, *AS, *AO, *SFAN, *SFAS, *SFAO; /* activations of this group: [M, KN/2], [M, 3KS/4], [M, KO] + scales */
+    const uint8_t *BN, *BS, *BO, *SFBN, *SFBS, *SFBO; /* its packed weights */
+    const void *bias_bf16;                             /* optional [N] */
+    void *D;                                           /* [M, N] bf16 */
+    int M;                                             /* token rows of this group (0 = skip) */
+} mm_group;
+int mm_matmul_grouped(const mm_group *groups, int ngroups, int N, int KN, int KS, int KO, int wmode, int flags, mm_stream_t stream);
+
+/*
  * QLinearLayer.forward for decode-sized inputs in ONE launch (reference: qLinearLayer.py:58-74 = reorder_quantize_x + matmul
  * (+ bias)): every workgroup quantizes the M activation rows into LDS itself and then streams its weight rows.  Bit-identical to
  * mm_reorder_quantize(MM_QUANT_MIXED) followed by mm_matmul.  mm_qlinear_decode_supported() returns 0 when the shape cannot run

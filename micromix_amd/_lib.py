@@ -17,7 +17,7 @@ EXPORTS = (
     "mm_version", "mm_strerror", "mm_last_error",
     "mm_sf_bytes_x", "mm_sf_bytes_w", "mm_sf_offset",
     "mm_reorder_quantize", "mm_reorder_quantize_gather", "mm_activate_quantize", "mm_downproj_quantize", "mm_matmul",
-    "mm_matmul_ws", "mm_matmul_workspace_bytes", "mm_rmsnorm_quantize", "mm_qlinear_decode", "mm_qlinear_decode_supported",
+    "mm_matmul_ws", "mm_matmul_workspace_bytes", "mm_rmsnorm_quantize", "mm_qlinear_decode", "mm_qlinear_decode_supported", "mm_matmul_grouped",
     "mm_diag_mfma", "mm_diag_hw_convert", "mm_diag_mfma_rate", "mm_diag_l2_bw", "mm_diag_set_clock_buffer",
     "mm_diag_set_kernel_events",
 )
@@ -27,6 +27,12 @@ MM_QUANT_MIXED, MM_QUANT_W4 = 0, 1
 MM_W_MATCH, MM_W_FP4 = 0, 1
 MM_ROUND_PER_SEGMENT, MM_ROUND_ONCE, MM_SPLIT_K_ALWAYS = 0, 1, 2
 MM_RMS_REFERENCE, MM_RMS_NO_INTEGER_ROUND = 0, 1
+
+class MMGroup(ctypes.Structure):
+    """mm_group of include/micromix_hip.h"""
+    _fields_ = [(n, ctypes.c_void_p) for n in ("AN", "AS", "AO", "SFAN", "SFAS", "SFAO", "BN", "BS", "BO", "SFBN", "SFBS", "SFBO",
+                                              "bias_bf16", "D")] + [("M", ctypes.c_int)]
+
 
 _lib = None
 
@@ -74,6 +80,8 @@ def load():
     lib.mm_qlinear_decode.argtypes = [vp] * 8 + [i] * 7 + [vp, vp, vp]
     lib.mm_qlinear_decode_supported.restype = i
     lib.mm_qlinear_decode_supported.argtypes = [i] * 5
+    lib.mm_matmul_grouped.restype = i
+    lib.mm_matmul_grouped.argtypes = [ctypes.POINTER(MMGroup), i, i, i, i, i, i, i, vp]
     lib.mm_matmul_ws.restype = i
     lib.mm_matmul_ws.argtypes = [vp] * 12 + [i] * 7 + [vp, vp, vp, ctypes.c_size_t, vp]
     lib.mm_matmul_workspace_bytes.restype = ctypes.c_size_t

@@ -184,6 +184,65 @@ int mm_matmul_ws(const uint8_t *AN, const uint8_t *BN, const uint8_t *AS, const 
     return e == hipSuccess ? MM_OK : fail_hip(e, "mm_matmul");
 }
 
+int mm_matmul_grouped(const mm_group *groups, int ngroups, int N, int KN, int KS, int KO, int wmode, int flags, mm_stream_t stream) {
+    if (ngroups < 0 || N < 0 || KN < 0 || KS < 0 || KO < 0 || (ngroups > 0 && !groups)) return MM_ERR_BAD_ARG;
+    if ((KN % 128) || (KS % 128) || (KO % 128)) return MM_ERR_BAD_SPLIT;
+    if (wmode != MM_W_MATCH && wmode != MM_W_FP4) return MM_ERR_BAD_ARG;
+    if (ngroups == 0 || N == 0) return MM_OK;
+    for (int i = 0; i < ngroups; ++i) {
+        const mm_group &g = groups[i];
+        if (g.M < 0) return MM_ERR_BAD_ARG;
+        if (g.M == 0) continue;
+        if (!g.D || (KN && (!g.AN || !g.BN || !g.SFAN || !g.SFBN)) || (KS && (!g.AS || !g.BS || !g.SFAS || !g.SFBS)) ||
+            (KO && (!g.AO || !g.BO || !g.SFAO || !g.SFBO)))
+            return MM_ERR_BAD_ARG;
+    }
+    // groups of at most 64 token rows share launches of the weight-streaming kernels (up to MM_MAX_GROUPS per launch); bigger
+    // groups fill the GPU by themselves and go through mm_matmul one by one
+    mm::GroupedGemmArgs ga;
+    int count = 0, max_m = 0;
+    auto flush = [&]() -> int {
+        if (count == 0) return MM_OK;
+        ga.ngroups = count;
+        hipError_t e = mm::launch_mx_gemm_skinny_grouped(ga, max_m, wmode == MM_W_FP4, (hipStream_t)stream);
+        count = 0;
+        max_m = 0;
+        return e == hipSuccess ? MM_OK : fail_hip(e, "mm_matmul_grouped");
+    };
+    for (int i = 0; i < ngroups; ++i) {
+        const mm_group &g = groups[i];
+        if (g.M == 0) continue;
+        if (g.M > 64 || KN + KS + KO == 0) {
+            const int st = mm_matmul(g.AN, g.BN, g.AS, g.BS, g.AO, g.BO, g.SFAN, g.SFBN, g.SFAS, g.SFBS, g.SFAO, g.SFBO, g.M, N, KN, KS,
+                                     KO, wmode, flags, g.bias_bf16, g.D, stream);
+            if (st != MM_OK) return st;
+            continue;
+        }
+        mm::GemmArgs &a = ga.g[count];
+        a.X[0] = g.AN; a.X[1] = g.AS; a.X[2] = g.AO;
+        a.W[0] = g.BN; a.W[1] = g.BS; a.W[2] = g.BO;
+        a.SFX[0] = g.SFAN; a.SFX[1] = g.SFAS; a.SFX[2] = g.SFAO;
+        a.SFW[0] = g.SFBN; a.SFW[1] = g.SFBS; a.SFW[2] = g.SFBO;
+        a.K[0] = KN; a.K[1] = KS; a.K[2] = KO;
+        a.M = g.M; a.N = N;
+        a.sfx_row_tiles = g.M / 128 + 1;
+        a.sfw_row_tiles = (N + 127) / 128;
+        a.round_per_segment = (flags & MM_ROUND_ONCE) ? 0 : 1;
+        a.bias = (const uint16_t *)g.bias_bf16;
+        a.D = (uint16_t *)g.D;
+        a.clock_out = nullptr;
+        a.ev_start = a.ev_stop = nullptr;
+        a.ws = nullptr; a.ws_bytes = 0; a.splits = 0; a.force_split = 0; a.n_tile0 = a.n_tiles = 0;
+        a.split_first[0] = a.split_first[1] = a.split_first[2] = a.split_first[3] = 0;
+        max_m = g.M > max_m ? g.M : max_m;
+        if (++count == mm::MM_MAX_GROUPS) {
+            const int st = flush();
+            if (st != MM_OK) return st;
+        }
+    }
+    return flush();
+}
+
 int mm_diag_set_kernel_events(void *start_event, void *stop_event) {
     g_ev_start = (hipEvent_t)start_event;
     g_ev_stop = (hipEvent_t)stop_event;

@@ -104,7 +104,7 @@ __device__ __forceinline__ void run_segment(v16f (&acc)[TM], const uint8_t *X, c
 }
 
 template <bool W4, int TM>
-__global__ void __launch_bounds__(NT) mx_gemm_skinny_kernel(GemmArgs a) {
+__device__ __forceinline__ void skinny_body(const GemmArgs &a) {
     __shared__ float red[NW][TM][16][64];
     const int n0 = blockIdx.x * BN;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -234,7 +234,7 @@ __device__ __forceinline__ void run_segment16(v4f (&acc)[T16], const uint8_t *X,
 }
 
 template <bool W4, int T16>
-__global__ void __launch_bounds__(NT) mx_gemm_skinny16_kernel(GemmArgs a) {
+__device__ __forceinline__ void skinny16_body(const GemmArgs &a) {
     __shared__ float red[NW][T16 * 4][64];
     const int n0 = blockIdx.x * BN16;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -287,6 +287,26 @@ __global__ void __launch_bounds__(NT) mx_gemm_skinny16_kernel(GemmArgs a) {
     }
 }
 
+template <bool W4, int TM>
+__global__ void __launch_bounds__(NT) mx_gemm_skinny_kernel(GemmArgs a) { skinny_body<W4, TM>(a); }
+template <bool W4, int T16>
+__global__ void __launch_bounds__(NT) mx_gemm_skinny16_kernel(GemmArgs a) { skinny16_body<W4, T16>(a); }
+
+// Grouped launch (MoE experts): blockIdx.y picks one of up to MM_MAX_GROUPS problems that share
+// N, the K split and the weight mode but have their own operands, outputs and token counts; the argument blocks travel in the
+// kernel arguments, so no device scratch is needed.  The token-tile count is the maximum over the groups (rows past a group's
+// M read as zeros and are not stored); a group with M = 0 returns at once.
+template <bool W4, int TM>
+__global__ void __launch_bounds__(NT) mx_gemm_skinny_grouped_kernel(GroupedGemmArgs ga) {
+    const GemmArgs &a = ga.g[blockIdx.y];
+    if (a.M > 0) skinny_body<W4, TM>(a);
+}
+template <bool W4, int T16>
+__global__ void __launch_bounds__(NT) mx_gemm_skinny16_grouped_kernel(GroupedGemmArgs ga) {
+    const GemmArgs &a = ga.g[blockIdx.y];
+    if (a.M > 0) skinny16_body<W4, T16>(a);
+}
+
 }  // namespace skinny
 
 hipError_t launch_mx_gemm_skinny(const GemmArgs &a, bool w4, hipStream_t stream) {
@@ -317,6 +337,43 @@ hipError_t launch_mx_gemm_skinny(const GemmArgs &a, bool w4, hipStream_t stream)
     } else {
         if (w4) hipLaunchKernelGGL((mx_gemm_skinny_kernel<true, 2>), dim3(blocks), dim3(NT), 0, stream, a);
         else hipLaunchKernelGGL((mx_gemm_skinny_kernel<false, 2>), dim3(blocks), dim3(NT), 0, stream, a);
+    }
+    return hipGetLastError();
+}
+
+// all groups must have M <= 64 and share N, K[], round_per_segment; returns hipErrorInvalidValue otherwise
+hipError_t launch_mx_gemm_skinny_grouped(const GroupedGemmArgs &ga, int max_m, bool w4, hipStream_t stream) {
+    using namespace skinny;
+    if (ga.ngroups < 1 || ga.ngroups > MM_MAX_GROUPS || max_m < 1 || max_m > 64) return hipErrorInvalidValue;
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = 256;
+    }
+    const int N = ga.g[0].N, blocks = (N + BN - 1) / BN;
+    // with G groups in one launch there are G x blocks workgroups: 16 features per workgroup while that still leaves CUs idle
+    if (2 * blocks * ga.ngroups <= cus) {
+        const dim3 grid((N + BN16 - 1) / BN16, ga.ngroups);
+#define MM_G16(T_)                                                                                                     \
+    do {                                                                                                               \
+        if (w4) hipLaunchKernelGGL((mx_gemm_skinny16_grouped_kernel<true, T_>), grid, dim3(NT), 0, stream, ga);       \
+        else hipLaunchKernelGGL((mx_gemm_skinny16_grouped_kernel<false, T_>), grid, dim3(NT), 0, stream, ga);         \
+    } while (0)
+        if (max_m <= 16) MM_G16(1);
+        else if (max_m <= 32) MM_G16(2);
+        else if (max_m <= 48) MM_G16(3);
+        else MM_G16(4);
+#undef MM_G16
+    } else {
+        const dim3 grid(blocks, ga.ngroups);
+        if (max_m <= 32) {
+            if (w4) hipLaunchKernelGGL((mx_gemm_skinny_grouped_kernel<true, 1>), grid, dim3(NT), 0, stream, ga);
+            else hipLaunchKernelGGL((mx_gemm_skinny_grouped_kernel<false, 1>), grid, dim3(NT), 0, stream, ga);
+        } else {
+            if (w4) hipLaunchKernelGGL((mx_gemm_skinny_grouped_kernel<true, 2>), grid, dim3(NT), 0, stream, ga);
+            else hipLaunchKernelGGL((mx_gemm_skinny_grouped_kernel<false, 2>), grid, dim3(NT), 0, stream, ga);
+        }
     }
     return hipGetLastError();
 }

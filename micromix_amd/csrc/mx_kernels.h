@@ -27,6 +27,12 @@ struct GemmArgs {
     unsigned long long *clock_out;  // diagnostics only (mm_diag_set_clock_buffer): per workgroup {shader cycles, 100 MHz ticks}
 };
 
+constexpr int MM_MAX_GROUPS = 8;   // argument blocks of one grouped launch travel in the kernel arguments (8 x ~230 B)
+struct GroupedGemmArgs {
+    GemmArgs g[MM_MAX_GROUPS];
+    int ngroups;
+};
+
 hipError_t launch_reorder_quantize(const void *src, int rows, int K, const int16_t *idx, int KN, int KS, int KO, bool w4,
                                    uint8_t *oN, uint8_t *oS, uint8_t *oO, uint8_t *sfN, uint8_t *sfS, uint8_t *sfO,
                                    hipStream_t stream);
@@ -42,6 +48,7 @@ hipError_t launch_qlinear_decode(const void *X, const int16_t *idx, const uint8_
 hipError_t launch_mx_gemm(const GemmArgs &a, bool w4, hipStream_t stream);
 hipError_t launch_mx_gemm256(const GemmArgs &a, bool w4, hipStream_t stream);
 hipError_t launch_mx_gemm_skinny(const GemmArgs &a, bool w4, hipStream_t stream);
+hipError_t launch_mx_gemm_skinny_grouped(const GroupedGemmArgs &ga, int max_m, bool w4, hipStream_t stream);
 size_t mx_gemm_workspace_bytes(int M, int N, const int K[3], bool force);  // 0 when mm_matmul would not split K for this shape
 
 }  // namespace mm

@@ -28,7 +28,7 @@ import torch
 from . import _lib
 
 __all__ = ["matmul", "reorder_quantize_x", "reorder_quantize_w", "reorder_quantize_w4", "activate_quantize_x",
-           "downproj_quantize_w", "downproj_quantize_w4", "rmsnorm_quantize_x", "qlinear_decode", "qlinear_decode_supported"]
+           "downproj_quantize_w", "downproj_quantize_w4", "rmsnorm_quantize_x", "qlinear_decode", "qlinear_decode_supported", "matmul_grouped"]
 
 
 def _stream_ptr(device) -> int:
@@ -215,6 +215,60 @@ def matmul(AN, BN, AS, BS, AO, BO, SFAN, SFBN, SFAS, SFBS, SFAO, SFBO, *, bias=N
     if st:
         _lib.check(st, "matmul")
     return out
+
+
+def matmul_grouped(As, Bs, *, biases=None, rounding="reference"):
+    """`[matmul(*interleave(A_g, B_g)) for g]` for groups that share N, the (KN, KS, KO) split and the weight mode -- MoE experts
+    (the per-expert loop of qMixtralLayer.py:507-519) -- in as few launches as possible: groups of <= 64 token rows run 8 per
+    launch.  As[g] = (AN, AS, AO, SFAN, SFAS, SFAO) as returned by reorder_quantize_x, Bs[g] = (BN, BS, BO, SFBN, SFBS, SFBO).
+    Returns the list of [M_g, N] bf16 outputs, bit-identical to the separate calls.  Not an export of the reference module."""
+    lib = _lib.load()
+    if len(As) != len(Bs) or (biases is not None and len(biases) != len(As)):
+        raise ValueError("As, Bs (and biases) must have one entry per group")
+    if not As:
+        return []
+    dev = As[0][0].device
+    index = dev.index
+    u8 = torch.uint8
+    BN0, BS0, BO0 = Bs[0][0], Bs[0][1], Bs[0][2]
+    N = BN0.size(0)
+    KN, KS, KO = As[0][0].size(1) * 2, As[0][1].size(1) * 4 // 3, As[0][2].size(1)
+    same = As[0][1].size(1) == BS0.size(1) and As[0][2].size(1) == BO0.size(1)
+    wmode = _lib.MM_W_MATCH if same else _lib.MM_W_FP4
+    wb = (KN // 2, KS // 4 * 3 if same else KS // 2, KO if same else KO // 2)
+    flags = _lib.MM_ROUND_PER_SEGMENT if rounding == "reference" else _lib.MM_ROUND_ONCE
+    if rounding not in ("reference", "fused"):
+        raise ValueError("rounding must be 'reference' or 'fused'")
+    arr = (_lib.MMGroup * len(As))()
+    outs = []
+    for g, (A, B) in enumerate(zip(As, Bs)):
+        for t in (*A, *B):
+            if not _ok(t, u8, index):
+                _check_tensor(t, f"group {g} operand", u8, dev)
+        M = A[0].size(0)
+        if (A[0].size(1) * 2, A[1].size(1) * 4 // 3, A[2].size(1)) != (KN, KS, KO) or A[1].size(0) != M or A[2].size(0) != M:
+            raise RuntimeError(f"group {g}: activation segments do not match the split of group 0")
+        if tuple(t.size(0) for t in B[:3]) != (N, N, N) or tuple(t.size(1) for t in B[:3]) != wb:
+            raise RuntimeError(f"group {g}: packed weights do not match N / split / weight mode of group 0")
+        if (A[3].numel() < _sf_bytes_w(M, KN) or A[4].numel() < _sf_bytes_w(M, KS) or A[5].numel() < _sf_bytes_w(M, KO)
+                or B[3].numel() < _sf_bytes_w(N, KN) or B[4].numel() < _sf_bytes_w(N, KS) or B[5].numel() < _sf_bytes_w(N, KO)):
+            raise RuntimeError(f"group {g}: a scale tensor is too small")
+        bias = biases[g] if biases is not None else None
+        if bias is not None and (not _ok(bias, torch.bfloat16, index) or bias.numel() != N):
+            raise RuntimeError(f"group {g}: bias must be a bfloat16 tensor with N elements")
+        out = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+        outs.append(out)
+        e = arr[g]
+        e.AN, e.AS, e.AO, e.SFAN, e.SFAS, e.SFAO = (_ptr(t) for t in A)
+        e.BN, e.BS, e.BO, e.SFBN, e.SFBS, e.SFBO = (_ptr(t) for t in B)
+        e.bias_bf16 = _ptr(bias) if bias is not None else None
+        e.D = _ptr(out)
+        e.M = M
+    with _on_device(index):
+        st = lib.mm_matmul_grouped(arr, len(As), N, KN, KS, KO, wmode, flags, _stream_ptr(dev))
+    if st:
+        _lib.check(st, "matmul_grouped")
+    return outs
 
 
 def qlinear_decode_supported(M, N, KN, KS, KO):

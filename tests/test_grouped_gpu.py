@@ -1,0 +1,53 @@
+"""GPU test of the grouped GEMM (MoE expert batching): bit-identical to one matmul per group."""
+import pytest
+
+from micromix_amd import mixedgemm
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("wmode", ("w4", "w"))
+@pytest.mark.parametrize("n,k,split,ms", [
+    (256, 512, (256, 128, 128), (3, 0, 17, 64, 1, 40, 8, 33, 5, 12)),        # ten groups: two launches, one empty group
+    (4096, 1024, (512, 0, 512), (4, 4, 9, 2)),                               # 16-feature kernel (4 x 128 workgroups)
+    (1024, 384, (128, 128, 128), (64, 100, 7, 300)),                         # groups above 64 rows fall back to mm_matmul
+    (14336, 256, (0, 0, 256), (2, 31)),                                      # many workgroups: the 32-feature kernel
+])
+def test_grouped_equals_per_group_matmul(dev, wmode, n, k, split, ms):
+    import torch
+    g = torch.Generator().manual_seed(n + k + len(ms))
+    As, Bs, biases, want = [], [], [], []
+    quant_w = mixedgemm.reorder_quantize_w4 if wmode == "w4" else mixedgemm.reorder_quantize_w
+    for i, m in enumerate(ms):
+        idx = torch.randperm(k, generator=g).to(torch.int16).to(dev)           # every expert has its own reorder index
+        w = (torch.randn((n, k), generator=g) * 0.05).to(torch.bfloat16).to(dev)
+        x = torch.randn((m, k), generator=g).to(torch.bfloat16).to(dev)
+        b = quant_w(w, idx, *split)
+        a = mixedgemm.reorder_quantize_x(x, idx, *split)
+        bias = torch.randn((n,), generator=g).to(torch.bfloat16).to(dev) if i % 2 else None
+        As.append(a); Bs.append(b); biases.append(bias)
+        want.append(mixedgemm.matmul(a[0], b[0], a[1], b[1], a[2], b[2], a[3], b[3], a[4], b[4], a[5], b[5], bias=bias, split_k=False))
+    for rounding in ("reference", "fused"):
+        if rounding == "fused":
+            want = [mixedgemm.matmul(a[0], b[0], a[1], b[1], a[2], b[2], a[3], b[3], a[4], b[4], a[5], b[5], bias=bi, split_k=False,
+                                     rounding="fused") for a, b, bi in zip(As, Bs, biases)]
+        got = mixedgemm.matmul_grouped(As, Bs, biases=biases, rounding=rounding)
+        torch.cuda.synchronize()
+        assert len(got) == len(ms)
+        for i, (y, ref) in enumerate(zip(got, want)):
+            assert y.shape == ref.shape and torch.equal(y, ref), (i, ms[i], rounding)
+
+
+def test_grouped_argument_checks(dev):
+    import torch
+    assert mixedgemm.matmul_grouped([], []) == []
+    k, split = 256, (128, 0, 128)
+    idx = torch.arange(k, dtype=torch.int16, device=dev)
+    w = torch.zeros((128, k), dtype=torch.bfloat16, device=dev)
+    x = torch.zeros((4, k), dtype=torch.bfloat16, device=dev)
+    a, b = mixedgemm.reorder_quantize_x(x, idx, *split), mixedgemm.reorder_quantize_w4(w, idx, *split)
+    other = mixedgemm.reorder_quantize_x(x, idx, 256, 0, 0)
+    with pytest.raises(RuntimeError):
+        mixedgemm.matmul_grouped([a, other], [b, b])
+    with pytest.raises(ValueError):
+        mixedgemm.matmul_grouped([a], [b, b])
