@@ -162,6 +162,16 @@ int mm_matmul_ws(const uint8_t *AN, const uint8_t *BN, const uint8_t *AS, const 
  * weight-streaming kernels, 8 groups per launch; larger groups run through mm_matmul one after the other.  Results are
  * bit-identical to ngroups calls of mm_matmul.  `groups` is a HOST array (copied into the kernel arguments).
  */
+typedef struct mm_quant_group {
+    const void *src_bf16;           /* [rows, K] bf16: the token rows routed to this expert */
+    const int16_t *reorder_index;   /* [K]: this expert's own index */
+    uint8_t *oN, *oS, *oO, *sfN, *sfS, *sfO; /* outputs as mm_reorder_quantize */
+    int rows;                        /* 0 = skip */
+} mm_quant_group;
+/* mm_reorder_quantize for `ngroups` independent row sets that share K and the split (the per-expert reorder_quantize_x calls of
+ * qMixtralLayer.py:507-519), 8 groups per launch; `groups` is a HOST array.  Bit-identical to the separate calls. */
+int mm_reorder_quantize_grouped(const mm_quant_group *groups, int ngroups, int K, int KN, int KS, int KO, int mode, mm_stream_t stream);
+
 typedef struct mm_group {
     const uint8_t *AN, *AS, *AO, *SFAN, *SFAS, *SFAO; /* activations of this group: [M, KN/2], [M, 3KS/4], [M, KO] + scales */
     const uint8_t *BN, *BS, *BO, *SFBN, *SFBS, *SFBO; /* its packed weights */

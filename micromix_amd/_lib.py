@@ -17,7 +17,7 @@ EXPORTS = (
     "mm_version", "mm_strerror", "mm_last_error",
     "mm_sf_bytes_x", "mm_sf_bytes_w", "mm_sf_offset",
     "mm_reorder_quantize", "mm_reorder_quantize_gather", "mm_activate_quantize", "mm_downproj_quantize", "mm_matmul",
-    "mm_matmul_ws", "mm_matmul_workspace_bytes", "mm_rmsnorm_quantize", "mm_qlinear_decode", "mm_qlinear_decode_supported", "mm_matmul_grouped",
+    "mm_matmul_ws", "mm_matmul_workspace_bytes", "mm_rmsnorm_quantize", "mm_qlinear_decode", "mm_qlinear_decode_supported", "mm_matmul_grouped", "mm_reorder_quantize_grouped",
     "mm_diag_mfma", "mm_diag_hw_convert", "mm_diag_mfma_rate", "mm_diag_l2_bw", "mm_diag_set_clock_buffer",
     "mm_diag_set_kernel_events",
 )
@@ -32,6 +32,11 @@ class MMGroup(ctypes.Structure):
     """mm_group of include/micromix_hip.h"""
     _fields_ = [(n, ctypes.c_void_p) for n in ("AN", "AS", "AO", "SFAN", "SFAS", "SFAO", "BN", "BS", "BO", "SFBN", "SFBS", "SFBO",
                                               "bias_bf16", "D")] + [("M", ctypes.c_int)]
+
+
+class MMQuantGroup(ctypes.Structure):
+    """mm_quant_group of include/micromix_hip.h"""
+    _fields_ = [(n, ctypes.c_void_p) for n in ("src_bf16", "reorder_index", "oN", "oS", "oO", "sfN", "sfS", "sfO")] + [("rows", ctypes.c_int)]
 
 
 _lib = None
@@ -80,6 +85,8 @@ def load():
     lib.mm_qlinear_decode.argtypes = [vp] * 8 + [i] * 7 + [vp, vp, vp]
     lib.mm_qlinear_decode_supported.restype = i
     lib.mm_qlinear_decode_supported.argtypes = [i] * 5
+    lib.mm_reorder_quantize_grouped.restype = i
+    lib.mm_reorder_quantize_grouped.argtypes = [ctypes.POINTER(MMQuantGroup), i, i, i, i, i, i, vp]
     lib.mm_matmul_grouped.restype = i
     lib.mm_matmul_grouped.argtypes = [ctypes.POINTER(MMGroup), i, i, i, i, i, i, i, vp]
     lib.mm_matmul_ws.restype = i

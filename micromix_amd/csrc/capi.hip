@@ -184,6 +184,47 @@ int mm_matmul_ws(const uint8_t *AN, const uint8_t *BN, const uint8_t *AS, const 
     return e == hipSuccess ? MM_OK : fail_hip(e, "mm_matmul");
 }
 
+int mm_reorder_quantize_grouped(const mm_quant_group *groups, int ngroups, int K, int KN, int KS, int KO, int mode, mm_stream_t stream) {
+    if (ngroups < 0 || (ngroups > 0 && !groups)) return MM_ERR_BAD_ARG;
+    if (!split_ok(K, KN, KS, KO)) return MM_ERR_BAD_SPLIT;
+    if (mode != MM_QUANT_MIXED && mode != MM_QUANT_W4) return MM_ERR_BAD_ARG;
+    if (K > 32768) return MM_ERR_BAD_ARG;
+    for (int i = 0; i < ngroups; ++i) {
+        const mm_quant_group &g = groups[i];
+        if (g.rows < 0) return MM_ERR_BAD_ARG;
+        if (g.rows == 0) continue;
+        if (!g.src_bf16 || !g.reorder_index || (KN && (!g.oN || !g.sfN)) || (KS && (!g.oS || !g.sfS)) || (KO && (!g.oO || !g.sfO)))
+            return MM_ERR_BAD_ARG;
+    }
+    mm::GroupedQuantArgs ga;
+    ga.K = K; ga.KN = KN; ga.KS = KS; ga.KO = KO;
+    int count = 0, max_rows = 0;
+    auto flush = [&]() -> int {
+        if (count == 0) return MM_OK;
+        ga.ngroups = count;
+        hipError_t e = mm::launch_reorder_quantize_grouped(ga, max_rows, mode == MM_QUANT_W4, (hipStream_t)stream);
+        count = 0;
+        max_rows = 0;
+        return e == hipSuccess ? MM_OK : fail_hip(e, "mm_reorder_quantize_grouped");
+    };
+    for (int i = 0; i < ngroups; ++i) {
+        const mm_quant_group &g = groups[i];
+        if (g.rows == 0) continue;
+        mm::QuantArgs &q = ga.g[count];
+        q.src = (const uint16_t *)g.src_bf16;
+        q.idx = g.reorder_index;
+        q.o[0] = g.oN; q.o[1] = g.oS; q.o[2] = g.oO;
+        q.sf[0] = g.sfN; q.sf[1] = g.sfS; q.sf[2] = g.sfO;
+        q.rows = g.rows;
+        max_rows = g.rows > max_rows ? g.rows : max_rows;
+        if (++count == mm::MM_MAX_GROUPS) {
+            const int st = flush();
+            if (st != MM_OK) return st;
+        }
+    }
+    return flush();
+}
+
 int mm_matmul_grouped(const mm_group *groups, int ngroups, int N, int KN, int KS, int KO, int wmode, int flags, mm_stream_t stream) {
     if (ngroups < 0 || N < 0 || KN < 0 || KS < 0 || KO < 0 || (ngroups > 0 && !groups)) return MM_ERR_BAD_ARG;
     if ((KN % 128) || (KS % 128) || (KO % 128)) return MM_ERR_BAD_SPLIT;

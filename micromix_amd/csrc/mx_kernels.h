@@ -33,6 +33,19 @@ struct GroupedGemmArgs {
     int ngroups;
 };
 
+struct QuantArgs {
+    const uint16_t *src;   // [rows, K] bf16
+    const int16_t *idx;    // [KN + KS + KO]
+    uint8_t *o[3];         // packed segments
+    uint8_t *sf[3];        // scale tensors
+    int rows;
+};
+struct GroupedQuantArgs {
+    QuantArgs g[MM_MAX_GROUPS];
+    int ngroups, K, KN, KS, KO;
+};
+hipError_t launch_reorder_quantize_grouped(const GroupedQuantArgs &ga, int max_rows, bool w4, hipStream_t stream);
+
 hipError_t launch_reorder_quantize(const void *src, int rows, int K, const int16_t *idx, int KN, int KS, int KO, bool w4,
                                    uint8_t *oN, uint8_t *oS, uint8_t *oO, uint8_t *sfN, uint8_t *sfS, uint8_t *sfO,
                                    hipStream_t stream);

@@ -24,11 +24,12 @@
 
 namespace mm {
 
-template <bool W4, int MAXT>
-__global__ void __launch_bounds__(MAXT)
-reorder_quantize_kernel(const uint16_t *__restrict__ src, int rows, int K, const int16_t *__restrict__ idx, int KN,
-                        int KS, int KO, uint8_t *__restrict__ oN, uint8_t *__restrict__ oS, uint8_t *__restrict__ oO,
-                        uint8_t *__restrict__ sfN, uint8_t *__restrict__ sfS, uint8_t *__restrict__ sfO) {
+// rows first_row, first_row + row_stride, ... of one [rows, K] matrix (one workgroup's share)
+template <bool W4>
+__device__ __forceinline__ void reorder_quantize_body(const uint16_t *__restrict__ src, int rows, int K, const int16_t *__restrict__ idx,
+                                                      int KN, int KS, int KO, uint8_t *__restrict__ oN, uint8_t *__restrict__ oS,
+                                                      uint8_t *__restrict__ oO, uint8_t *__restrict__ sfN, uint8_t *__restrict__ sfS,
+                                                      uint8_t *__restrict__ sfO, int first_row, int row_stride) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int G = (KN + KS + KO) >> 5;  // groups produced; K is the input row length (>= 32 * G)
     const int g = threadIdx.x;
@@ -56,7 +57,7 @@ reorder_quantize_kernel(const uint16_t *__restrict__ src, int rows, int K, const
     else { seg = 2; j = g - gN - gS; kseg = KO; }
 
     uint4 stage[4];
-    int r = blockIdx.x;
+    int r = first_row;
     if (r < rows) {
         const uint4 *grow = reinterpret_cast<const uint4 *>(src + (size_t)r * K);
 #pragma unroll
@@ -73,8 +74,8 @@ reorder_quantize_kernel(const uint16_t *__restrict__ src, int rows, int K, const
         }
     }
     __syncthreads();
-    for (; r < rows; r += gridDim.x) {
-        const int rn = r + gridDim.x;
+    for (; r < rows; r += row_stride) {
+        const int rn = r + row_stride;
         if (rn < rows) {
             const uint4 *grow = reinterpret_cast<const uint4 *>(src + (size_t)rn * K);
 #pragma unroll
@@ -125,6 +126,24 @@ reorder_quantize_kernel(const uint16_t *__restrict__ src, int rows, int K, const
     }
 }
 
+template <bool W4, int MAXT>
+__global__ void __launch_bounds__(MAXT)
+reorder_quantize_kernel(const uint16_t *__restrict__ src, int rows, int K, const int16_t *__restrict__ idx, int KN,
+                        int KS, int KO, uint8_t *__restrict__ oN, uint8_t *__restrict__ oS, uint8_t *__restrict__ oO,
+                        uint8_t *__restrict__ sfN, uint8_t *__restrict__ sfS, uint8_t *__restrict__ sfO) {
+    reorder_quantize_body<W4>(src, rows, K, idx, KN, KS, KO, oN, oS, oO, sfN, sfS, sfO, blockIdx.x, gridDim.x);
+}
+
+// Grouped launch (MoE experts: every expert quantizes its own token rows with its own reorder index; reference: the
+// per-expert reorder_quantize_x calls of qMixtralLayer.py:507-519): blockIdx.y picks one of up to MM_MAX_GROUPS argument blocks.
+template <bool W4, int MAXT>
+__global__ void __launch_bounds__(MAXT) reorder_quantize_grouped_kernel(GroupedQuantArgs ga) {
+    const QuantArgs &q = ga.g[blockIdx.y];
+    if ((int)blockIdx.x < q.rows)
+        reorder_quantize_body<W4>(q.src, q.rows, ga.K, q.idx, ga.KN, ga.KS, ga.KO, q.o[0], q.o[1], q.o[2], q.sf[0], q.sf[1], q.sf[2],
+                                  blockIdx.x, gridDim.x);
+}
+
 hipError_t launch_reorder_quantize(const void *src, int rows, int K, const int16_t *idx, int KN, int KS, int KO, bool w4,
                                    uint8_t *oN, uint8_t *oS, uint8_t *oO, uint8_t *sfN, uint8_t *sfS, uint8_t *sfO,
                                    hipStream_t stream) {
@@ -149,6 +168,26 @@ hipError_t launch_reorder_quantize(const void *src, int rows, int K, const int16
     blocks = rows < blocks ? rows : blocks;
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds, stream, (const uint16_t *)src, rows, K, idx, KN, KS, KO, oN,
                        oS, oO, sfN, sfS, sfO);
+    return hipGetLastError();
+}
+
+hipError_t launch_reorder_quantize_grouped(const GroupedQuantArgs &ga, int max_rows, bool w4, hipStream_t stream) {
+    if (ga.ngroups < 1 || ga.ngroups > MM_MAX_GROUPS || max_rows < 1) return hipErrorInvalidValue;
+    const int G = (ga.KN + ga.KS + ga.KO) / 32, stagers = ga.K / 32;
+    const int threads = ((G > stagers ? G : stagers) + 63) / 64 * 64;
+    const size_t lds = (size_t)ga.K * 2;
+    auto kern = threads <= 256 ? (w4 ? reorder_quantize_grouped_kernel<true, 256> : reorder_quantize_grouped_kernel<false, 256>)
+                               : (w4 ? reorder_quantize_grouped_kernel<true, 1024> : reorder_quantize_grouped_kernel<false, 1024>);
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kern), threads, lds) != hipSuccess ||
+        per_cu < 1)
+        per_cu = 1;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    int bx = cus * per_cu / ga.ngroups;   // one resident wave of workgroups shared by the groups
+    bx = bx < 1 ? 1 : bx;
+    bx = max_rows < bx ? max_rows : bx;
+    hipLaunchKernelGGL(kern, dim3(bx, ga.ngroups), dim3(threads), lds, stream, ga);
     return hipGetLastError();
 }
 

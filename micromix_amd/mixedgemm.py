@@ -28,7 +28,7 @@ import torch
 from . import _lib
 
 __all__ = ["matmul", "reorder_quantize_x", "reorder_quantize_w", "reorder_quantize_w4", "activate_quantize_x",
-           "downproj_quantize_w", "downproj_quantize_w4", "rmsnorm_quantize_x", "qlinear_decode", "qlinear_decode_supported", "matmul_grouped"]
+           "downproj_quantize_w", "downproj_quantize_w4", "rmsnorm_quantize_x", "qlinear_decode", "qlinear_decode_supported", "matmul_grouped", "reorder_quantize_x_grouped"]
 
 
 def _stream_ptr(device) -> int:
@@ -215,6 +215,45 @@ def matmul(AN, BN, AS, BS, AO, BO, SFAN, SFBN, SFAS, SFBS, SFAO, SFBO, *, bias=N
     if st:
         _lib.check(st, "matmul")
     return out
+
+
+def reorder_quantize_x_grouped(Xs, reorder_indices, KN, KS, KO):
+    """`[reorder_quantize_x(X_g, idx_g, KN, KS, KO) for g]` for row sets that share K and the split (the tokens routed to each MoE
+    expert, every expert with its own reorder index; qMixtralLayer.py:507-519), 8 groups per launch, bit-identical to the
+    separate calls.  Returns a list of 6-tuples.  Not an export of the reference module."""
+    lib = _lib.load()
+    if len(Xs) != len(reorder_indices):
+        raise ValueError("one reorder index per group")
+    if not Xs:
+        return []
+    KN, KS, KO = int(KN), int(KS), int(KO)
+    dev = Xs[0].device
+    index = dev.index
+    K = Xs[0].size(1)
+    if KN < 0 or KS < 0 or KO < 0 or KN % 128 or KS % 128 or KO % 128 or KN + KS + KO != K:
+        _lib.check(_lib.MM_ERR_BAD_SPLIT, "reorder_quantize_x")
+    arr = (_lib.MMQuantGroup * len(Xs))()
+    res = []
+    u8 = torch.uint8
+    for g, (X, idx) in enumerate(zip(Xs, reorder_indices)):
+        if not (_ok(X, torch.bfloat16, index) and _ok(idx, torch.int16, index)) or X.dim() != 2 or X.size(1) != K or idx.numel() != K:
+            _check_tensor(X, f"X[{g}]", torch.bfloat16, dev)
+            _check_tensor(idx, f"reorder_index[{g}]", torch.int16, dev)
+            raise RuntimeError(f"group {g}: X must be [rows, {K}] and its reorder index must have {K} entries")
+        rows = X.size(0)
+        out = (torch.empty((rows, KN // 2), dtype=u8, device=dev), torch.empty((rows, KS // 4 * 3), dtype=u8, device=dev),
+               torch.empty((rows, KO), dtype=u8, device=dev), torch.empty((_sf_bytes_x(rows, KN),), dtype=u8, device=dev),
+               torch.empty((_sf_bytes_x(rows, KS),), dtype=u8, device=dev), torch.empty((_sf_bytes_x(rows, KO),), dtype=u8, device=dev))
+        res.append(out)
+        e = arr[g]
+        e.src_bf16, e.reorder_index = _ptr(X), _ptr(idx)
+        e.oN, e.oS, e.oO, e.sfN, e.sfS, e.sfO = (_ptr(t) for t in out)
+        e.rows = rows
+    with _on_device(index):
+        st = lib.mm_reorder_quantize_grouped(arr, len(Xs), K, KN, KS, KO, _lib.MM_QUANT_MIXED, _stream_ptr(dev))
+    if st:
+        _lib.check(st, "reorder_quantize_x")
+    return res
 
 
 def matmul_grouped(As, Bs, *, biases=None, rounding="reference"):

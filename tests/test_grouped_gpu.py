@@ -51,3 +51,27 @@ def test_grouped_argument_checks(dev):
         mixedgemm.matmul_grouped([a, other], [b, b])
     with pytest.raises(ValueError):
         mixedgemm.matmul_grouped([a], [b, b])
+
+
+@pytest.mark.parametrize("k,split,rows", [(512, (256, 128, 128), (3, 0, 17, 64, 1, 40, 8, 33, 5, 130)),
+                                          (4096, (3584, 256, 256), (2, 2, 1, 9)), (14336, (12544, 1024, 768), (1, 4))])
+def test_grouped_quantizer_equals_separate_calls(dev, k, split, rows):
+    """reorder_quantize_x_grouped: every expert's rows with its own reorder index, byte for byte the separate calls"""
+    import torch
+    from conftest import u8
+    from oracle import mx_oracle as o
+    g = torch.Generator().manual_seed(k + len(rows))
+    Xs = [torch.randn((r, k), generator=g).to(torch.bfloat16).to(dev) for r in rows]
+    idxs = [torch.randperm(k, generator=g).to(torch.int16).to(dev) for _ in rows]
+    got = mixedgemm.reorder_quantize_x_grouped(Xs, idxs, *split)
+    torch.cuda.synchronize()
+    assert len(got) == len(rows)
+    for X, idx, q, r in zip(Xs, idxs, got, rows):
+        want = mixedgemm.reorder_quantize_x(X, idx, *split)
+        for i, (a, b) in enumerate(zip(q, want)):
+            assert a.shape == b.shape
+            if i < 3:
+                assert torch.equal(a, b)
+            elif r:
+                off = o.sf_valid_offsets(r, split[i - 3])
+                assert (u8(a)[off] == u8(b)[off]).all()
