@@ -14,7 +14,7 @@ CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libmicromix_hip.so")
 SOURCES = ["capi.hip", "reorder_quantize.hip", "direct_quantize.hip", "rmsnorm_quantize.hip", "mx_gemm.hip", "mx_gemm256.hip", "mx_gemm_skinny.hip", "qlinear_decode.hip", "diag.hip"]
-HEADERS = ["mx_common.h", "mx_kernels.h", "mx_acc_regs.h", "mx_gemm_tile.inc", "mx_group_convert.h", os.path.join("..", "..", "include", "micromix_hip.h")]
+HEADERS = ["mx_common.h", "mx_kernels.h", "mx_acc_regs.h", "mx_gemm_tile.inc", "mx_gemm_tile_vgpr.inc", "mx_group_convert.h", os.path.join("..", "..", "include", "micromix_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-shared", "-fgpu-rdc=0" if False else "-fno-gpu-rdc",
          "-Wall", "-Wno-unused-function"]
 
