@@ -59,14 +59,25 @@ namespace mm {
 
 #define MM_NS g256
 #define MM_TM 2
+#define MM_TN 4
 #include "mx_gemm_tile.inc"
 #undef MM_NS
 #undef MM_TM
+#undef MM_TN
 #define MM_NS g128
 #define MM_TM 1
+#define MM_TN 4
 #include "mx_gemm_tile.inc"
 #undef MM_NS
 #undef MM_TM
+#undef MM_TN
+#define MM_NS g64
+#define MM_TM 1
+#define MM_TN 2
+#include "mx_gemm_tile.inc"
+#undef MM_NS
+#undef MM_TM
+#undef MM_TN
 
 
 // ---------------------------------------------------------------------------------------------------------
@@ -131,7 +142,7 @@ static int env_int(const char *name, int dflt) {
 // 128-deep slab in ~0.7 us (DMA-latency bound), and every split adds tiles * 128 KiB of fp32 partial sums that are
 // written and read back at ~4 TB/s (0.064 us per tile and split), plus ~5 us for the second launch:
 //     t(S) = 0.7 * slabs / S + 0.064 * tiles * S (+ 5)   ->   S* = 3.3 * sqrt(slabs / tiles)
-// Split only when that beats the unsplit 0.7 * slabs by 15 %.  `force` (MM_SPLIT_K_ALWAYS, tests and tuning) skips the
+// Split only when that beats the unsplit launch (128 x 128 tiles at these tile counts, ~0.5 us per slab) by 15 %.  `force` (MM_SPLIT_K_ALWAYS, tests and tuning) skips the
 // model.  MICROMIX_SPLITK=0 disables splitting, =S pins the split count.
 static int plan_splits(int M, int N, const int K[3], bool force, int first[4]) {
     static const int pinned = env_int("MICROMIX_SPLITK", -1);
@@ -154,7 +165,7 @@ static int plan_splits(int M, int N, const int K[3], bool force, int first[4]) {
         S = (int)(3.3f * sqrtf((float)total / (float)tiles) + 0.5f);
         S = S < nonempty ? nonempty : S;
         S = S > cap ? cap : S;
-        const float unsplit = 0.7f * total, split = 0.7f * total / S + 0.064f * tiles * S + 5.0f;
+        const float unsplit = 0.5f * total, split = 0.7f * total / S + 0.064f * tiles * S + 5.0f;   // unsplit: 128 x 128 tiles, ~0.5 us per slab
         if (S < 2 || split > 0.85f * unsplit) return 0;
     }
     S = S > cap ? cap : S;
@@ -236,7 +247,15 @@ hipError_t launch_mx_gemm256(const GemmArgs &a, bool w4, hipStream_t stream) {
     // flop; a round of 128-row tiles takes ~0.62 of a round of 256-row tiles (measured).  So 128-row tiles pay exactly when
     // they still fit in ONE round (tiles128 <= cus, i.e. at most half of the CUs would get a 256-row tile): M=2048, N=4096
     // 46.5 -> 33 us; with 160 256-row tiles (320 128-row tiles = two rounds) the 256-row tiles win, 62 vs 76 us.
-    const bool use128 = force == 128 || (force != 256 && tiles128 <= cus);
+    const bool use128 = force == 128 || (force != 256 && force != 64 && tiles128 <= cus);
+    // ... and when even the 128-row tiles would occupy at most half of the CUs, 128 x 128 tiles double the workgroups once
+    // more (1.5x the L2->LDS bytes per flop, which does not matter while half of the chip idles): M = 1024, N = 4096.
+    const int tiles64 = ((a.M + 127) / 128) * ((a.N + 127) / 128);
+    if (force == 64 || (force == 0 && 2 * tiles128 <= cus && tiles64 <= cus)) {
+        static bool done64[2] = {false, false};
+        if (w4) return launch_tile(g64::mx_gemm256_kernel<true, false>, done64[0], g64::Lds<true>::TOTAL, tiles64, g64::NT, a, stream);
+        return launch_tile(g64::mx_gemm256_kernel<false, false>, done64[1], g64::Lds<false>::TOTAL, tiles64, g64::NT, a, stream);
+    }
     // Tail balancing: tiles256 = q * CUs + R runs q + 1 rounds and the last one leaves CUs idle.
     // When R <= CUs / 2 and R is a whole number of tile columns, those columns are run as 128-row tiles instead (2R
     // workgroups of half the work: the last round takes half the time).  gate/up at M = 4096: 896 tiles = 3.5 rounds.
