@@ -106,9 +106,10 @@ def test_new_entry_points_validate_on_the_host():
     assert lib.mm_matmul_workspace_bytes(16, 4096, 0, 0, 4096, 1, 0) == 0
     assert lib.mm_matmul_workspace_bytes(4096, 4096, 0, 0, 4096, 1, 0) == 0
     assert lib.mm_matmul_workspace_bytes(128, 4096, 0, 0, 100, 1, 0) == 0
-    ws = lib.mm_matmul_workspace_bytes(128, 4096, 0, 0, 4096, 1, 0)
+    ws = lib.mm_matmul_workspace_bytes(128, 4096, 7168, 512, 6656, 1, 0)   # down_proj: 16 tiles, 112 slabs -> split
     assert ws > 0 and ws % (128 * 1024) == 0                       # whole 128 KiB partial-sum blocks
-    assert lib.mm_matmul_workspace_bytes(128, 4096, 0, 0, 4096, 1, _lib.MM_SPLIT_K_ALWAYS) >= ws
+    assert lib.mm_matmul_workspace_bytes(128, 4096, 7168, 512, 6656, 1, _lib.MM_SPLIT_K_ALWAYS) >= ws
+    assert lib.mm_matmul_workspace_bytes(128, 4096, 0, 0, 4096, 1, _lib.MM_SPLIT_K_ALWAYS) > 0
     assert lib.mm_qlinear_decode_supported(1, 4096, 2048, 128, 1920) == 2
     assert lib.mm_qlinear_decode_supported(9, 4096, 2048, 128, 1920) == 0
     assert lib.mm_qlinear_decode_supported(4, 4096, 100, 0, 0) == 0
