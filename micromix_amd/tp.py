@@ -108,16 +108,44 @@ class TPShardedLinear:
     def quantize_x(self, x: torch.Tensor):
         return None if self.empty else self.ops.quantize_x(x, self.index, *self.shard_widths)
 
-    def matmul_allreduce(self, qx, out: torch.Tensor | None = None, m: int | None = None) -> torch.Tensor:
+    @staticmethod
+    def _row_chunk(qx, widths, r0, r1):
+        """rows [r0, r1) of a quantized activation tuple (r0 a multiple of 128): the packed segments are row-major and the scale
+        tensors are tiled by 128 rows (512 bytes per row tile and 128-column slab), so a 128-aligned row range is contiguous."""
+        out = [t[r0:r1] for t in qx[:3]]
+        for sf, kseg in zip(qx[3:], widths):
+            out.append(sf[(r0 // 128) * (kseg // 128) * 512:])
+        return tuple(out)
+
+    def matmul_allreduce(self, qx, out: torch.Tensor | None = None, m: int | None = None, chunk_rows: int | None = None) -> torch.Tensor:
+        """partial GEMM of this rank's K-shard + ONE sum over the ranks.  With `chunk_rows` (a multiple of 128; default 1024 when
+        there are at least two chunks) the rows are processed in chunks whose all-reduce is issued asynchronously, so the
+        collective of chunk i runs on RCCL's stream while the GEMM of chunk i+1 runs on the compute stream."""
         import torch.distributed as dist
         if self.empty:       # more ranks than 128-column granules: contribute zeros
             if out is None:
                 raise ValueError("an empty shard needs `out` (or use forward)")
             out.zero_()
+            if self.world > 1:
+                dist.all_reduce(out, op=dist.ReduceOp.SUM, group=self.group)
         else:
-            out = self.ops.matmul(qx, self.packed_w, out=out)
-        if self.world > 1:
-            dist.all_reduce(out, op=dist.ReduceOp.SUM, group=self.group)
+            rows = qx[0].shape[0] if qx[0].shape[1] else (qx[1].shape[0] if qx[1].shape[1] else qx[2].shape[0])
+            if chunk_rows is None:
+                chunk_rows = 1024
+            if self.world > 1 and chunk_rows % 128 == 0 and rows >= 2 * chunk_rows:
+                if out is None:
+                    out = torch.empty((rows, self.N), dtype=torch.bfloat16, device=qx[0].device)
+                works = []
+                for r0 in range(0, rows, chunk_rows):
+                    r1 = min(rows, r0 + chunk_rows)
+                    self.ops.matmul(self._row_chunk(qx, self.shard_widths, r0, r1), self.packed_w, out=out[r0:r1])
+                    works.append(dist.all_reduce(out[r0:r1], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                for w in works:
+                    w.wait()
+            else:
+                out = self.ops.matmul(qx, self.packed_w, out=out)
+                if self.world > 1:
+                    dist.all_reduce(out, op=dist.ReduceOp.SUM, group=self.group)
         if self.bias is not None:
             out += self.bias
         return out

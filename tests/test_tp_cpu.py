@@ -111,3 +111,30 @@ def test_two_rank_gloo_matches_unsharded_oracle():
     S = sum(np.abs(ai).astype(np.float64) @ np.abs(bi).astype(np.float64).T for ai, bi in zip(a, b))
     assert np.all(np.abs(got - f64) <= 2.0 ** -7 * (np.abs(f64) + 0.25 * S) + 1e-30)
     assert np.linalg.norm(got - f64) / np.linalg.norm(f64) < 4e-3
+
+
+def _worker_chunked(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        m, n, k, split = 300, 32, 512, (256, 128, 128)
+        tb = lambda bits: torch.from_numpy(bits.view(np.int16).copy()).view(torch.bfloat16)
+        x, w, idx = tb(lcg.bf16_normalish(11, (m, k))), tb(lcg.bf16_normalish(12, (n, k), exp_center=122)), torch.from_numpy(lcg.permutation(13, k))
+        layer = tp.TPShardedLinear(w, idx, *split, rank=rank, world=world, group=dist.group.WORLD, ops=OracleOps)
+        qx = layer.quantize_x(x)
+        whole = layer.matmul_allreduce(qx, out=torch.empty((m, n), dtype=torch.bfloat16), chunk_rows=4096)      # one all-reduce
+        chunked = layer.matmul_allreduce(qx, out=torch.empty((m, n), dtype=torch.bfloat16), chunk_rows=128)   # 128 + 128 + 44 rows
+        ret[rank] = bool(torch.equal(whole, chunked))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_chunked_async_allreduce_equals_single_allreduce():
+    """rows processed in 128-aligned chunks with an asynchronous all-reduce per chunk (compute/communication overlap on the
+    GPU) give exactly the single-all-reduce result"""
+    world = 2
+    port = 31500 + os.getpid() % 2000
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_worker_chunked, args=(world, port, ret), nprocs=world, join=True)
+        assert dict(ret) == {0: True, 1: True}
