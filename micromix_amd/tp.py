@@ -118,9 +118,11 @@ class TPShardedLinear:
         return tuple(out)
 
     def matmul_allreduce(self, qx, out: torch.Tensor | None = None, m: int | None = None, chunk_rows: int | None = None) -> torch.Tensor:
-        """partial GEMM of this rank's K-shard + ONE sum over the ranks.  With `chunk_rows` (a multiple of 128; default 1024 when
-        there are at least two chunks) the rows are processed in chunks whose all-reduce is issued asynchronously, so the
-        collective of chunk i runs on RCCL's stream while the GEMM of chunk i+1 runs on the compute stream."""
+        """partial GEMM of this rank's K-shard + ONE sum over the ranks.  With `chunk_rows` (a multiple of 128) the rows are
+        processed in chunks whose all-reduce is issued asynchronously, so the collective of chunk i runs on RCCL's stream while
+        the GEMM of chunk i+1 runs on the compute stream.  Off by default: for one 4096-wide linear the all-reduce is many times
+        longer than the sharded GEMM and a ring collective is most efficient in one large message, so chunking only pays when
+        the GEMM share is large (long K per rank, small world)."""
         import torch.distributed as dist
         if self.empty:       # more ranks than 128-column granules: contribute zeros
             if out is None:
@@ -130,9 +132,7 @@ class TPShardedLinear:
                 dist.all_reduce(out, op=dist.ReduceOp.SUM, group=self.group)
         else:
             rows = qx[0].shape[0] if qx[0].shape[1] else (qx[1].shape[0] if qx[1].shape[1] else qx[2].shape[0])
-            if chunk_rows is None:
-                chunk_rows = 1024
-            if self.world > 1 and chunk_rows % 128 == 0 and rows >= 2 * chunk_rows:
+            if self.world > 1 and chunk_rows is not None and chunk_rows % 128 == 0 and rows > chunk_rows:
                 if out is None:
                     out = torch.empty((rows, self.N), dtype=torch.bfloat16, device=qx[0].device)
                 works = []

@@ -122,7 +122,7 @@ def _worker_chunked(rank, world, port, ret):
         x, w, idx = tb(lcg.bf16_normalish(11, (m, k))), tb(lcg.bf16_normalish(12, (n, k), exp_center=122)), torch.from_numpy(lcg.permutation(13, k))
         layer = tp.TPShardedLinear(w, idx, *split, rank=rank, world=world, group=dist.group.WORLD, ops=OracleOps)
         qx = layer.quantize_x(x)
-        whole = layer.matmul_allreduce(qx, out=torch.empty((m, n), dtype=torch.bfloat16), chunk_rows=4096)      # one all-reduce
+        whole = layer.matmul_allreduce(qx, out=torch.empty((m, n), dtype=torch.bfloat16))                       # one all-reduce
         chunked = layer.matmul_allreduce(qx, out=torch.empty((m, n), dtype=torch.bfloat16), chunk_rows=128)   # 128 + 128 + 44 rows
         ret[rank] = bool(torch.equal(whole, chunked))
     finally:
