@@ -1,12 +1,12 @@
 """First-contact hardware probe: prints (does not assert) how the GPU compares with the oracle.
-Run on the GPU box:  python tools/gpu_probe.py"""
+Run on the GPU box:  python tests/gpu_probe.py   (a script, not collected by pytest; it lives here because only tests use the oracle)"""
 import os
 import sys
 import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # tests/ -> repo root
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
