@@ -23,14 +23,18 @@ namespace mm {
 template <int EL, bool INT_ROUND>
 __device__ __forceinline__ uint32_t rms_quantize_group(const uint8_t *__restrict__ row, const uint32_t (&ix)[16],
                                                        const uint32_t (&wg)[16], float rvar, uint8_t *__restrict__ out) {
+    typedef float f2 __attribute__((ext_vector_type(2)));   // two-wide fp32 arithmetic (v_pk_mul_f32 / v_pk_add_f32)
     uint32_t v[16];
     us2 amax2 = {0, 0};
+    const f2 rvar2 = {rvar, rvar};
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-        const float x0 = bf16_bits_to_f32(*reinterpret_cast<const uint16_t *>(row + (ix[i] & 0xFFFFu)));
-        const float x1 = bf16_bits_to_f32(*reinterpret_cast<const uint16_t *>(row + (ix[i] >> 16)));
+        const f2 x = {bf16_bits_to_f32(*reinterpret_cast<const uint16_t *>(row + (ix[i] & 0xFFFFu))),
+                      bf16_bits_to_f32(*reinterpret_cast<const uint16_t *>(row + (ix[i] >> 16)))};
+        const f2 w = {bf16_bits_to_f32(wg[i] & 0xFFFFu), bf16_bits_to_f32(wg[i] >> 16)};
         // (x * w) is exact in fp32 (two 8-bit significands); one rounding in the multiply by rvar, one to bf16
-        v[i] = pack_bf16x2((x0 * bf16_bits_to_f32(wg[i] & 0xFFFFu)) * rvar, (x1 * bf16_bits_to_f32(wg[i] >> 16)) * rvar);
+        const f2 r = (x * w) * rvar2;
+        v[i] = pack_bf16x2(r[0], r[1]);
         const uint32_t mag = v[i] & 0x7FFF7FFFu;
         us2 m;
         __builtin_memcpy(&m, &mag, 4);
@@ -43,11 +47,15 @@ __device__ __forceinline__ uint32_t rms_quantize_group(const uint8_t *__restrict
         return 0u;
     }
     if constexpr (INT_ROUND) {
+        // round(v * 2^-e) half away from zero = trunc(t + copysign(0.5, t)).  The reference's clamp to +-FMAX cannot bite here:
+        // e is the smallest exponent with FMAX * 2^e >= amax, so |t| <= FMAX, an integer.
         const float rs = __uint_as_float((uint32_t)(127 - e) << 23);  // 2^-e: v * 2^-e is exact
+        const f2 rs2 = {rs, rs};
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            v[i] = pack_bf16x2(integer_round_clamp<EL>(bf16_bits_to_f32(v[i] & 0xFFFFu) * rs),
-                               integer_round_clamp<EL>(bf16_bits_to_f32(v[i] >> 16) * rs));
+            f2 t = f2{bf16_bits_to_f32(v[i] & 0xFFFFu), bf16_bits_to_f32(v[i] >> 16)} * rs2;
+            t = t + f2{__builtin_copysignf(0.5f, t[0]), __builtin_copysignf(0.5f, t[1])};
+            v[i] = pack_bf16x2(__builtin_truncf(t[0]), __builtin_truncf(t[1]));
         }
         convert_group<EL>(v, 1.0f, out);
     } else {
