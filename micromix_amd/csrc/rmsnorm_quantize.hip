@@ -78,7 +78,16 @@ rmsnorm_quantize_kernel(const uint16_t *__restrict__ src, const uint16_t *__rest
     int P = 64;
     while (P < T) P <<= 1;
 
+    // the norm weights of this thread's 32 columns: the weight vector is staged in LDS (coalesced) and gathered from there
+    // with the same byte offsets as the row (32 scattered 2-byte global loads per thread cost more than the two rows a
+    // workgroup typically processes)
     uint32_t ix[16], wg[16];
+    if (active) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            reinterpret_cast<uint4 *>(smem)[i * T + g] = reinterpret_cast<const uint4 *>(weight)[i * T + g];
+    }
+    __syncthreads();
     if (active) {
         const uint4 *p = reinterpret_cast<const uint4 *>(idx + (size_t)g * 32);
 #pragma unroll
@@ -87,12 +96,14 @@ rmsnorm_quantize_kernel(const uint16_t *__restrict__ src, const uint16_t *__rest
             const uint32_t w[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const uint32_t i0 = w[k] & 0xFFFFu, i1 = w[k] >> 16;
-                ix[4 * i + k] = (i0 << 1) | (i1 << 17);            // byte offsets into the staged row
-                wg[4 * i + k] = (uint32_t)weight[i0] | ((uint32_t)weight[i1] << 16);
+                const uint32_t b0 = (w[k] & 0xFFFFu) << 1, b1 = (w[k] >> 16) << 1;   // byte offsets into a staged [K] bf16 vector
+                ix[4 * i + k] = b0 | (b1 << 16);
+                wg[4 * i + k] = (uint32_t)*reinterpret_cast<const uint16_t *>(smem + b0) |
+                                ((uint32_t)*reinterpret_cast<const uint16_t *>(smem + b1) << 16);
             }
         }
     }
+    __syncthreads();   // the row staging below reuses the same LDS bytes
     const int gN = KN >> 5, gS = KS >> 5;
     int seg, j, kseg;
     if (g < gN) { seg = 0; j = g; kseg = KN; }
