@@ -1,0 +1,131 @@
+// Stand-alone C++ client of the C ABI (no torch, no Python): what a maintainer of the reference's bindings.cpp would link against.
+//   hipcc --offload-arch=gfx950 -O2 -I include examples/cabi_demo.cpp -L micromix_amd/lib -lmicromix_hip -Wl,-rpath,$PWD/micromix_amd/lib -o examples/cabi_demo
+// It packs a weight matrix once (reorder_quantize_w4), quantizes activations (reorder_quantize_x), runs the fused GEMM, and checks
+// two exact properties that need no oracle: the result is deterministic, and adding 1 to every activation scale byte doubles it.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "micromix_hip.h"
+
+#define HIP_OK(x)                                                                      \
+    do {                                                                               \
+        hipError_t e_ = (x);                                                           \
+        if (e_ != hipSuccess) {                                                        \
+            std::fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_));               \
+            return 2;                                                                  \
+        }                                                                              \
+    } while (0)
+#define MM_CALL(x)                                                                     \
+    do {                                                                               \
+        int s_ = (x);                                                                  \
+        if (s_ != MM_OK) {                                                             \
+            std::fprintf(stderr, "%s: %s %s\n", #x, mm_strerror(s_), mm_last_error()); \
+            return 3;                                                                  \
+        }                                                                              \
+    } while (0)
+
+static uint16_t bf16(float f) {   // round to nearest even
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+static float from_bf16(uint16_t b) {
+    uint32_t u = (uint32_t)b << 16;
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+
+struct Quantized {
+    uint8_t *seg[3] = {nullptr, nullptr, nullptr}, *sf[3] = {nullptr, nullptr, nullptr};
+    size_t sf_bytes[3] = {0, 0, 0};
+};
+
+int main(int argc, char **argv) {
+    const int M = argc > 1 ? std::atoi(argv[1]) : 512, N = 1024, K = 2048, KN = 1024, KS = 128, KO = 896;
+    std::printf("libmicromix_hip %d: QLinear forward M=%d N=%d K=%d split=(%d,%d,%d), w4 weights\n", mm_version(), M, N, K, KN, KS, KO);
+    uint64_t lcg = 12345;
+    auto rnd = [&]() { lcg = lcg * 6364136223846793005ull + 1442695040888963407ull; return (float)((lcg >> 40) & 0xFFFF) / 32768.0f - 1.0f; };
+    std::vector<uint16_t> hx((size_t)M * K), hw((size_t)N * K);
+    for (auto &v : hx) v = bf16(rnd() * 2.0f);
+    for (auto &v : hw) v = bf16(rnd() * 0.05f);
+    std::vector<int16_t> hidx(K);
+    for (int i = 0; i < K; ++i) hidx[i] = (int16_t)((i * 389) % K);   // 389 is coprime to 2048: a permutation
+    uint16_t *dx, *dw, *dD;
+    int16_t *didx;
+    HIP_OK(hipMalloc(&dx, hx.size() * 2));
+    HIP_OK(hipMalloc(&dw, hw.size() * 2));
+    HIP_OK(hipMalloc(&didx, K * 2));
+    HIP_OK(hipMalloc(&dD, (size_t)M * N * 2));
+    HIP_OK(hipMemcpy(dx, hx.data(), hx.size() * 2, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(dw, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(didx, hidx.data(), K * 2, hipMemcpyHostToDevice));
+    const int widths[3] = {KN, KS, KO};
+    auto alloc = [&](Quantized &q, int rows, bool weight, bool w4) -> int {
+        for (int s = 0; s < 3; ++s) {
+            const size_t row_bytes = (w4 || s == 0) ? widths[s] / 2 : (s == 1 ? widths[s] / 4 * 3 : widths[s]);
+            q.sf_bytes[s] = weight ? mm_sf_bytes_w(rows, widths[s]) : mm_sf_bytes_x(rows, widths[s]);
+            HIP_OK(hipMalloc(&q.seg[s], rows * row_bytes + 16));
+            HIP_OK(hipMalloc(&q.sf[s], q.sf_bytes[s] + 16));
+        }
+        return 0;
+    };
+    Quantized qw, qx;
+    if (alloc(qw, N, true, true) || alloc(qx, M, false, false)) return 2;
+    hipStream_t stream;
+    HIP_OK(hipStreamCreate(&stream));
+    MM_CALL(mm_reorder_quantize(dw, N, K, didx, KN, KS, KO, MM_QUANT_W4, qw.seg[0], qw.seg[1], qw.seg[2], qw.sf[0], qw.sf[1], qw.sf[2], stream));
+    MM_CALL(mm_reorder_quantize(dx, M, K, didx, KN, KS, KO, MM_QUANT_MIXED, qx.seg[0], qx.seg[1], qx.seg[2], qx.sf[0], qx.sf[1], qx.sf[2], stream));
+    const size_t ws_bytes = mm_matmul_workspace_bytes(M, N, KN, KS, KO, MM_W_FP4, MM_ROUND_PER_SEGMENT);
+    void *ws = nullptr;
+    if (ws_bytes) HIP_OK(hipMalloc(&ws, ws_bytes));
+    auto gemm = [&]() {
+        return mm_matmul_ws(qx.seg[0], qw.seg[0], qx.seg[1], qw.seg[1], qx.seg[2], qw.seg[2], qx.sf[0], qw.sf[0], qx.sf[1], qw.sf[1], qx.sf[2],
+                            qw.sf[2], M, N, KN, KS, KO, MM_W_FP4, MM_ROUND_PER_SEGMENT, nullptr, dD, ws, ws_bytes, stream);
+    };
+    std::vector<uint16_t> d1((size_t)M * N), d2(d1.size()), d3(d1.size());
+    MM_CALL(gemm());
+    HIP_OK(hipMemcpyAsync(d1.data(), dD, d1.size() * 2, hipMemcpyDeviceToHost, stream));
+    MM_CALL(gemm());
+    HIP_OK(hipMemcpyAsync(d2.data(), dD, d2.size() * 2, hipMemcpyDeviceToHost, stream));
+    // +1 on every activation scale byte (UE8M0) doubles every block scale, hence the product, exactly
+    for (int s = 0; s < 3; ++s) {
+        if (!widths[s]) continue;
+        std::vector<uint8_t> sf(qx.sf_bytes[s]);
+        HIP_OK(hipMemcpyAsync(sf.data(), qx.sf[s], sf.size(), hipMemcpyDeviceToHost, stream));
+        HIP_OK(hipStreamSynchronize(stream));
+        for (auto &b : sf) b = (uint8_t)(b + 1);
+        HIP_OK(hipMemcpyAsync(qx.sf[s], sf.data(), sf.size(), hipMemcpyHostToDevice, stream));
+        HIP_OK(hipStreamSynchronize(stream));
+    }
+    MM_CALL(gemm());
+    HIP_OK(hipMemcpyAsync(d3.data(), dD, d3.size() * 2, hipMemcpyDeviceToHost, stream));
+    HIP_OK(hipStreamSynchronize(stream));
+    size_t nondet = 0, nonlinear = 0;
+    double sum = 0;
+    for (size_t i = 0; i < d1.size(); ++i) {
+        nondet += d1[i] != d2[i];
+        nonlinear += from_bf16(d3[i]) != 2.0f * from_bf16(d1[i]);
+        sum += from_bf16(d1[i]);
+    }
+    // timing
+    hipEvent_t e0, e1;
+    HIP_OK(hipEventCreate(&e0));
+    HIP_OK(hipEventCreate(&e1));
+    for (int i = 0; i < 10; ++i) MM_CALL(gemm());
+    HIP_OK(hipEventRecord(e0, stream));
+    for (int i = 0; i < 100; ++i) MM_CALL(gemm());
+    HIP_OK(hipEventRecord(e1, stream));
+    HIP_OK(hipEventSynchronize(e1));
+    float ms = 0;
+    HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+    std::printf("checksum %.4f, run-to-run differences %zu, scale-linearity violations %zu, workspace %zu bytes, %.1f us per GEMM\n", sum, nondet,
+                nonlinear, ws_bytes, ms * 10.0f);
+    return (nondet || nonlinear) ? 1 : 0;
+}
