@@ -103,7 +103,8 @@ int mm_reorder_quantize_gather(const void *src_bf16, int rows, int K_in, const i
  * Reorder-free quantizers (reference: mgemm/src/activate.cu:44-202, 208-500; bindings.cpp:307-387).  Natural column order,
  * scale = amax > 1e-6 ? 2^ceil(log2(amax/FMAX)) : 1.0, a single RNE rounding from fp32.  Every SF buffer holds
  * mm_sf_bytes_x(rows, Kseg) bytes (the reference sizes the weight variants that way too, bindings.cpp:348-350).
- *   mm_activate_quantize : v = silu(A) * B, A and B [rows, KN+KS+KO] bf16 -> fp4 | fp6 | fp8   (activate_quantize_x)
+ *   mm_activate_quantize : v = silu(A) * B, A and B [rows, KN+KS+KO] bf16 -> fp4 | fp6 | fp8   (activate_quantize_x); silu in fp32
+ *                          with the hardware exp2 / reciprocal (a few fp32 ulps, as the reference's CUDA expf)
  *   mm_downproj_quantize : v = W;  mode MM_QUANT_MIXED -> fp4 | fp6 | fp8 (downproj_quantize_w),
  *                                  mode MM_QUANT_W4    -> fp4 | fp4 | fp4 (downproj_quantize_w4)
  */
