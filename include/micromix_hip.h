@@ -160,8 +160,8 @@ int mm_matmul_ws(const uint8_t *AN, const uint8_t *BN, const uint8_t *AS, const 
  * Grouped GEMM (MoE experts; reference caller: the per-expert loop of model/qMixtralLayer.py:507-519, one matmul per expert and
  * linear): `ngroups` independent products D_g = matmul(A_g, B_g) that share N, the (KN, KS, KO) split, the weight mode and the
  * flags but have their own operands, token counts and outputs.  Groups of at most 64 token rows share launches of the
- * weight-streaming kernels, 8 groups per launch; larger groups run through mm_matmul one after the other.  Results are
- * bit-identical to ngroups calls of mm_matmul.  `groups` is a HOST array (copied into the kernel arguments).
+ * weight-streaming kernels, larger groups launches of the tiled kernels, 8 groups per launch.  Results are bit-identical to
+ * ngroups calls of mm_matmul (which never splits K).  `groups` is a HOST array (copied into the kernel arguments).
  */
 typedef struct mm_quant_group {
     const void *src_bf16;           /* [rows, K] bf16: the token rows routed to this expert */

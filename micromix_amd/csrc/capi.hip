@@ -238,28 +238,9 @@ int mm_matmul_grouped(const mm_group *groups, int ngroups, int N, int KN, int KS
             (KO && (!g.AO || !g.BO || !g.SFAO || !g.SFBO)))
             return MM_ERR_BAD_ARG;
     }
-    // groups of at most 64 token rows share launches of the weight-streaming kernels (up to MM_MAX_GROUPS per launch); bigger
-    // groups fill the GPU by themselves and go through mm_matmul one by one
-    mm::GroupedGemmArgs ga;
-    int count = 0, max_m = 0;
-    auto flush = [&]() -> int {
-        if (count == 0) return MM_OK;
-        ga.ngroups = count;
-        hipError_t e = mm::launch_mx_gemm_skinny_grouped(ga, max_m, wmode == MM_W_FP4, (hipStream_t)stream);
-        count = 0;
-        max_m = 0;
-        return e == hipSuccess ? MM_OK : fail_hip(e, "mm_matmul_grouped");
-    };
-    for (int i = 0; i < ngroups; ++i) {
-        const mm_group &g = groups[i];
-        if (g.M == 0) continue;
-        if (g.M > 64 || KN + KS + KO == 0) {
-            const int st = mm_matmul(g.AN, g.BN, g.AS, g.BS, g.AO, g.BO, g.SFAN, g.SFBN, g.SFAS, g.SFBS, g.SFAO, g.SFBO, g.M, N, KN, KS,
-                                     KO, wmode, flags, g.bias_bf16, g.D, stream);
-            if (st != MM_OK) return st;
-            continue;
-        }
-        mm::GemmArgs &a = ga.g[count];
+    // groups of at most 64 token rows share launches of the weight-streaming kernels, larger groups launches of the tiled
+    // kernels (up to MM_MAX_GROUPS argument blocks per launch, carried in the kernel arguments)
+    auto fill = [&](mm::GemmArgs &a, const mm_group &g) {
         a.X[0] = g.AN; a.X[1] = g.AS; a.X[2] = g.AO;
         a.W[0] = g.BN; a.W[1] = g.BS; a.W[2] = g.BO;
         a.SFX[0] = g.SFAN; a.SFX[1] = g.SFAS; a.SFX[2] = g.SFAO;
@@ -275,13 +256,54 @@ int mm_matmul_grouped(const mm_group *groups, int ngroups, int N, int KN, int KS
         a.ev_start = a.ev_stop = nullptr;
         a.ws = nullptr; a.ws_bytes = 0; a.splits = 0; a.force_split = 0; a.n_tile0 = a.n_tiles = 0;
         a.split_first[0] = a.split_first[1] = a.split_first[2] = a.split_first[3] = 0;
-        max_m = g.M > max_m ? g.M : max_m;
-        if (++count == mm::MM_MAX_GROUPS) {
-            const int st = flush();
-            if (st != MM_OK) return st;
+    };
+    if (KN + KS + KO == 0) {   // no segment: every output is zero (gemm.cu:48-50)
+        for (int i = 0; i < ngroups; ++i)
+            if (groups[i].M) {
+                const int st = mm_matmul(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                         nullptr, groups[i].M, N, 0, 0, 0, wmode, flags, nullptr, groups[i].D, stream);
+                if (st != MM_OK) return st;
+            }
+        return MM_OK;
+    }
+    mm::GroupedGemmArgs small;
+    mm::GroupedTileArgs big;
+    int nsmall = 0, nbig = 0, max_m = 0;
+    auto flush_small = [&]() -> int {
+        if (nsmall == 0) return MM_OK;
+        small.ngroups = nsmall;
+        hipError_t e = mm::launch_mx_gemm_skinny_grouped(small, max_m, wmode == MM_W_FP4, (hipStream_t)stream);
+        nsmall = 0;
+        max_m = 0;
+        return e == hipSuccess ? MM_OK : fail_hip(e, "mm_matmul_grouped");
+    };
+    auto flush_big = [&]() -> int {
+        if (nbig == 0) return MM_OK;
+        big.ngroups = nbig;
+        hipError_t e = mm::launch_mx_gemm256_grouped(big, wmode == MM_W_FP4, (hipStream_t)stream);
+        nbig = 0;
+        return e == hipSuccess ? MM_OK : fail_hip(e, "mm_matmul_grouped");
+    };
+    for (int i = 0; i < ngroups; ++i) {
+        const mm_group &g = groups[i];
+        if (g.M == 0) continue;
+        if (g.M > 64) {
+            fill(big.g[nbig], g);
+            if (++nbig == mm::MM_MAX_GROUPS) {
+                const int st = flush_big();
+                if (st != MM_OK) return st;
+            }
+        } else {
+            fill(small.g[nsmall], g);
+            max_m = g.M > max_m ? g.M : max_m;
+            if (++nsmall == mm::MM_MAX_GROUPS) {
+                const int st = flush_small();
+                if (st != MM_OK) return st;
+            }
         }
     }
-    return flush();
+    const int st = flush_small();
+    return st != MM_OK ? st : flush_big();
 }
 
 int mm_diag_set_kernel_events(void *start_event, void *stop_event) {

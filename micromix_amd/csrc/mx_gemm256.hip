@@ -282,4 +282,48 @@ hipError_t launch_mx_gemm256(const GemmArgs &a, bool w4, hipStream_t stream) {
     return launch_tile(g128::mx_gemm256_kernel<false, false>, done[3], g128::Lds<false>::TOTAL, tiles128, g128::NT, a, stream);
 }
 
+// grouped launch of the tiled kernels: the tile size is chosen for the sum of the groups' tiles with the same round rule as a
+// single problem (no split-K, no tail balancing)
+hipError_t launch_mx_gemm256_grouped(GroupedTileArgs &ga, bool w4, hipStream_t stream) {
+    if (ga.ngroups < 1 || ga.ngroups > MM_MAX_GROUPS) return hipErrorInvalidValue;
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = 256;
+    }
+    const int N = ga.g[0].N;
+    auto tiles = [&](int bm, int bn) {
+        int t = 0;
+        for (int i = 0; i < ga.ngroups; ++i) t += ((ga.g[i].M + bm - 1) / bm) * ((N + bn - 1) / bn);
+        return t;
+    };
+    const int t128 = tiles(128, 256), t64 = tiles(128, 128);
+    int bm, bn;
+    if (2 * t128 <= cus && t64 <= cus) { bm = 128; bn = 128; }
+    else if (t128 <= cus) { bm = 128; bn = 256; }
+    else { bm = 256; bn = 256; }
+    ga.first_block[0] = 0;
+    for (int i = 0; i < ga.ngroups; ++i)
+        ga.first_block[i + 1] = ga.first_block[i] + ((ga.g[i].M + bm - 1) / bm) * ((N + bn - 1) / bn);
+    for (int i = ga.ngroups + 1; i <= MM_MAX_GROUPS; ++i) ga.first_block[i] = ga.first_block[ga.ngroups];
+    const int total = ga.first_block[ga.ngroups];
+    static bool done[6] = {false, false, false, false, false, false};
+    auto go = [&](auto kern, bool &d, int lds, int threads) -> hipError_t {
+        if (!d) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            if (e != hipSuccess) return e;
+            d = true;
+        }
+        hipLaunchKernelGGL(kern, dim3(total), dim3(threads), lds, stream, ga);
+        return hipGetLastError();
+    };
+    if (bm == 256) return w4 ? go(g256::mx_gemm256_grouped_kernel<true>, done[0], g256::Lds<true>::TOTAL, g256::NT)
+                             : go(g256::mx_gemm256_grouped_kernel<false>, done[1], g256::Lds<false>::TOTAL, g256::NT);
+    if (bn == 256) return w4 ? go(g128::mx_gemm256_grouped_kernel<true>, done[2], g128::Lds<true>::TOTAL, g128::NT)
+                             : go(g128::mx_gemm256_grouped_kernel<false>, done[3], g128::Lds<false>::TOTAL, g128::NT);
+    return w4 ? go(g64::mx_gemm256_grouped_kernel<true>, done[4], g64::Lds<true>::TOTAL, g64::NT)
+              : go(g64::mx_gemm256_grouped_kernel<false>, done[5], g64::Lds<false>::TOTAL, g64::NT);
+}
+
 }  // namespace mm

@@ -33,6 +33,13 @@ struct GroupedGemmArgs {
     int ngroups;
 };
 
+struct GroupedTileArgs {
+    GemmArgs g[MM_MAX_GROUPS];
+    int first_block[MM_MAX_GROUPS + 1];   // prefix sum of the groups' tile counts
+    int ngroups;
+};
+hipError_t launch_mx_gemm256_grouped(GroupedTileArgs &ga, bool w4, hipStream_t stream);   // fills first_block[]
+
 struct QuantArgs {
     const uint16_t *src;   // [rows, K] bf16
     const int16_t *idx;    // [KN + KS + KO]

@@ -10,7 +10,9 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize("n,k,split,ms", [
     (256, 512, (256, 128, 128), (3, 0, 17, 64, 1, 40, 8, 33, 5, 12)),        # ten groups: two launches, one empty group
     (4096, 1024, (512, 0, 512), (4, 4, 9, 2)),                               # 16-feature kernel (4 x 128 workgroups)
-    (1024, 384, (128, 128, 128), (64, 100, 7, 300)),                         # groups above 64 rows fall back to mm_matmul
+    (1024, 384, (128, 128, 128), (64, 100, 7, 300)),                         # small and large groups mixed
+    (512, 256, (128, 0, 128), (128, 200, 65, 512, 300, 96, 1000, 70, 130)),  # nine large groups: two launches of the tiled kernels
+    (2048, 512, (256, 128, 128), (700, 1100)),                               # enough tiles for the 256-row tiles
     (14336, 256, (0, 0, 256), (2, 31)),                                      # many workgroups: the 32-feature kernel
 ])
 def test_grouped_equals_per_group_matmul(dev, wmode, n, k, split, ms):

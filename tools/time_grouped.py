@@ -22,7 +22,7 @@ for name, N, K, split in (("w1/w3 (each)", 14336, 4096, (3584, 256, 256)), ("w2"
     idxs = [torch.randperm(K, generator=g).to(torch.int16).to(dev) for _ in range(E)]
     Bs = [mixedgemm.reorder_quantize_w4(w, i, *split) for w, i in zip(ws, idxs)]
     del ws
-    for ms in ((1,) * 8, (2,) * 8, (8,) * 8, (32,) * 8, (3, 0, 9, 1, 0, 20, 2, 5)):
+    for ms in ((1,) * 8, (8,) * 8, (3, 0, 9, 1, 0, 20, 2, 5), (128,) * 8, (256,) * 8, (100, 300, 64, 200, 150, 90, 500, 120)):
         As = [mixedgemm.reorder_quantize_x(torch.randn((m, K), generator=g).to(torch.bfloat16).to(dev), i, *split) for m, i in zip(ms, idxs)]
         outs = [torch.empty((m, N), dtype=torch.bfloat16, device=dev) for m in ms]
         arr = (_lib.MMGroup * E)()
