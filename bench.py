@@ -257,6 +257,24 @@ def main():
             q = mixedgemm.reorder_quantize_x(x, idx, *SPLIT)
             mixedgemm.matmul(q[0], b[0], q[1], b[1], q[2], b[2], q[3], b[3], q[4], b[4], q[5], b[5], out=out)
         t_fwd = timed(fwd)
+        fwd_launch = "stream launches"
+        if graph is not None:       # the same K forwards as one hipGraph (as the GEMM steps above)
+            try:
+                gq = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gq):
+                    for _ in range(args.steps):
+                        fwd()
+                gq.replay()
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                gq.replay()
+                torch.cuda.synchronize()
+                t_graph = (time.perf_counter() - t) / args.steps
+                if t_graph < t_fwd:
+                    t_fwd, fwd_launch = t_graph, "one hipGraph of K forwards"
+                del gq
+            except Exception as e:
+                print(f"[bench] hipGraph capture of the forward failed ({e})", file=sys.stderr)
         # quantizer kernel alone: direct C-ABI calls on preallocated outputs (the op-level call spends ~20 us of host
         # time on six allocations, which would hide the 11 us kernel)
         lib = _lib.load()
@@ -273,7 +291,7 @@ def main():
         t_m = timed(lambda: mixedgemm.matmul(am[0], bm[0], am[1], bm[1], am[2], bm[2], am[3], bm[3], am[4], bm[4], am[5], bm[5], out=out))
         q_bytes = 2 * M * K + M * K + M * K // 32 + 2 * K
         result["qlinear"] = {
-            "tokens_per_s": round(M / t_fwd, 1), "forward_us": round(t_fwd * 1e6, 2),
+            "tokens_per_s": round(M / t_fwd, 1), "forward_us": round(t_fwd * 1e6, 2), "forward_launch": fwd_launch,
             "quantize_x_kernel_us": round(t_q * 1e6, 2), "quantize_x_GBps": round(q_bytes / t_q / 1e9, 1),
             "quantize_x_frac_of_8TBps": round(q_bytes / t_q / 8e12, 4),
             "gemm_w_mode_tflops": round(flop / t_w / 1e12, 2),
