@@ -196,38 +196,24 @@ int mm_qlinear_decode(const void *X_bf16, const int16_t *reorder_index, const ui
                       const uint8_t *SFBN, const uint8_t *SFBS, const uint8_t *SFBO, int M, int N, int KN, int KS, int KO,
                       int wmode, int flags, const void *bias_bf16, void *D_bf16, mm_stream_t stream);
 
+/* bindings.cpp:700 `m.def("test_function", ...)`: the reference module's liveness probe; returns the same constant string. */
+const char *mm_test_function(void);
+
 /*
- * Hardware diagnostics (not on the product path; used by the GPU tests to pin register
- * layouts and the oracle's encoders against the CDNA4 hardware).
- *   mm_diag_mfma: one wave issues one v_mfma_scale_f32_{32x32x64,16x16x128}_f8f6f4.
- *     shape 32|16; el_a/el_b 0=fp4 1=fp6(E3M2) 2=fp8(E4M3); opsel 0..3 applied to both scales;
- *     a_regs/b_regs [64 lanes][8] int32; scale_a/scale_b [64] int32; out [64][16|4] float.
- *   mm_diag_hw_convert: v_cvt_scalef32_pk_{fp4,fp8}_bf16 / pk32_bf6_bf16 on n (multiple of 32)
- *     bf16 values with one scale; out_codes gets one element code per byte.
+ * Measurement hooks (used by bench.py and tools/gemm_clock.py; they change no result).  Both are THREAD-LOCAL: they affect
+ * only launches made by the calling thread, so concurrent users of the library never see each other's hooks.
+ *
+ * mm_diag_set_kernel_events: while a pair of hipEvent_t is registered, every tiled-GEMM launch (M > 64) of this thread
+ *   attaches them to its own dispatch (hipExtLaunchKernel start/stop events), so hipEventElapsedTime gives the kernel's
+ *   duration as rocprofv3 reports it, without the launch gap that events recorded around the call include.  NULL, NULL disables.
+ * mm_diag_set_clock_buffer: when a device buffer of 4 x 8 bytes per workgroup is registered, the large-M GEMM kernel stores
+ *   {main-loop s_memtime delta, main-loop s_memrealtime delta, start tick, end-of-epilogue tick delta} of every workgroup
+ *   there (in-kernel clock = ratio x 100 MHz); NULL disables.
+ * The hardware microbenchmarks and probes (mm_diag_mfma, mm_diag_hw_convert, mm_diag_mfma_rate, mm_diag_l2_bw) are NOT part of
+ * this library: they live in libmicromix_diag.so, declared in include/micromix_diag.h.
  */
-int mm_diag_mfma(int shape, int el_a, int el_b, int opsel, const void *a_regs, const void *b_regs, const void *scale_a,
-                 const void *scale_b, void *out, mm_stream_t stream);
-int mm_diag_hw_convert(const void *src_bf16, int n, float scale, int el, uint8_t *out_codes, mm_stream_t stream);
-/* Issue-rate microbenchmark: `blocks` workgroups of 4 waves, each wave issues iters*8 independent scaled
- * MFMAs on register operands taken from seed_regs ([128][8] int32).  flops = blocks*4*iters*8*2*M*N*K. */
-int mm_diag_mfma_rate(int shape, int el_a, int el_b, int blocks, int iters, const void *seed_regs, void *sink,
-                      mm_stream_t stream);
-
-/* Diagnostics: when a device buffer of 4 x 8 bytes per workgroup is registered, the large-M GEMM kernel stores
- * {main-loop s_memtime delta, main-loop s_memrealtime delta, start tick, end-of-epilogue tick delta} of every workgroup
- * there (in-kernel clock = ratio x 100 MHz); NULL disables. */
 int mm_diag_set_clock_buffer(void *buf);
-
-/* Diagnostics: while a pair of hipEvent_t is registered, every tiled-GEMM launch (M > 64) attaches them to its own dispatch
- * (hipExtLaunchKernel start/stop events), so hipEventElapsedTime gives the kernel's duration as rocprofv3 reports it,
- * without the launch gap that events recorded around the call include.  NULL, NULL disables.  Used by bench.py. */
 int mm_diag_set_kernel_events(void *start_event, void *stop_event);
-
-/* L2 -> CU read-bandwidth microbenchmark (kernel-developer tool): `blocks` workgroups each move kb_per_iter KiB per
- * iteration from a hot region; mode 0 = register loads, 1 = contiguous LDS-DMA, 2 = LDS-DMA of 8 x 128-byte rows
- * `stride` bytes apart. */
-int mm_diag_l2_bw(const void *buf, unsigned region, int stride, int kb_per_iter, int iters, int mode, int blocks, void *sink,
-                  mm_stream_t stream);
 
 #ifdef __cplusplus
 }

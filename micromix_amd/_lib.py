@@ -18,9 +18,11 @@ EXPORTS = (
     "mm_sf_bytes_x", "mm_sf_bytes_w", "mm_sf_offset",
     "mm_reorder_quantize", "mm_reorder_quantize_gather", "mm_activate_quantize", "mm_downproj_quantize", "mm_matmul",
     "mm_matmul_ws", "mm_matmul_workspace_bytes", "mm_rmsnorm_quantize", "mm_qlinear_decode", "mm_qlinear_decode_supported", "mm_matmul_grouped", "mm_reorder_quantize_grouped",
-    "mm_diag_mfma", "mm_diag_hw_convert", "mm_diag_mfma_rate", "mm_diag_l2_bw", "mm_diag_set_clock_buffer",
-    "mm_diag_set_kernel_events",
+    "mm_test_function", "mm_diag_set_clock_buffer", "mm_diag_set_kernel_events",
 )
+# every symbol include/micromix_diag.h declares (libmicromix_diag.so: hardware probes for tests/tools, never used by the ops)
+DIAG_LIB_PATH = os.environ.get("MICROMIX_DIAG_LIB") or os.path.join(_PKG, "lib", "libmicromix_diag.so")
+DIAG_EXPORTS = ("mm_diag_mfma", "mm_diag_hw_convert", "mm_diag_mfma_rate", "mm_diag_l2_bw")
 
 MM_OK, MM_ERR_BAD_SPLIT, MM_ERR_BAD_ARG, MM_ERR_LAUNCH, MM_ERR_UNSUPPORTED, MM_ERR_NO_DEVICE = range(6)
 MM_QUANT_MIXED, MM_QUANT_W4 = 0, 1
@@ -93,6 +95,28 @@ def load():
     lib.mm_matmul_ws.argtypes = [vp] * 12 + [i] * 7 + [vp, vp, vp, ctypes.c_size_t, vp]
     lib.mm_matmul_workspace_bytes.restype = ctypes.c_size_t
     lib.mm_matmul_workspace_bytes.argtypes = [i] * 7
+    lib.mm_test_function.restype = ctypes.c_char_p
+    lib.mm_test_function.argtypes = []
+    lib.mm_diag_set_clock_buffer.restype = i
+    lib.mm_diag_set_clock_buffer.argtypes = [vp]
+    lib.mm_diag_set_kernel_events.restype = i
+    lib.mm_diag_set_kernel_events.argtypes = [vp, vp]
+    _lib = lib
+    return lib
+
+
+_diag = None
+
+
+def load_diag():
+    """libmicromix_diag.so (include/micromix_diag.h): hardware probes and microbenchmarks for tests/ and tools/."""
+    global _diag
+    if _diag is not None:
+        return _diag
+    if not os.path.exists(DIAG_LIB_PATH):
+        raise MicroMixLibraryError(f"{DIAG_LIB_PATH} is missing: build it with `python -m micromix_amd.build`")
+    lib = ctypes.CDLL(DIAG_LIB_PATH)
+    vp, i = ctypes.c_void_p, ctypes.c_int
     lib.mm_diag_mfma.restype = i
     lib.mm_diag_mfma.argtypes = [i, i, i, i, vp, vp, vp, vp, vp, vp]
     lib.mm_diag_hw_convert.restype = i
@@ -101,11 +125,7 @@ def load():
     lib.mm_diag_mfma_rate.argtypes = [i, i, i, i, i, vp, vp, vp]
     lib.mm_diag_l2_bw.restype = i
     lib.mm_diag_l2_bw.argtypes = [vp, ctypes.c_uint, i, i, i, i, i, vp, vp]
-    lib.mm_diag_set_clock_buffer.restype = i
-    lib.mm_diag_set_clock_buffer.argtypes = [vp]
-    lib.mm_diag_set_kernel_events.restype = i
-    lib.mm_diag_set_kernel_events.argtypes = [vp, vp]
-    _lib = lib
+    _diag = lib
     return lib
 
 

@@ -1,6 +1,11 @@
-"""Build recipe for libmicromix_hip.so (gfx950 only): a plain hipcc invocation, in-tree output.
+"""Build recipe for the gfx950 libraries: plain hipcc invocations, in-tree output.
 
     python -m micromix_amd.build [--force] [--keep-temps]
+
+  lib/libmicromix_hip.so   the product library (include/micromix_hip.h)
+  lib/libmicromix_diag.so  hardware probes / microbenchmarks for tests and tools (include/micromix_diag.h); not loaded by the ops
+
+Every source is compiled to its own object (in parallel, only when it or a header changed) and linked with hipcc.
 """
 from __future__ import annotations
 
@@ -8,47 +13,75 @@ import os
 import shutil
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
+OBJDIR = os.path.join(LIBDIR, "obj")
 LIB = os.path.join(LIBDIR, "libmicromix_hip.so")
-SOURCES = ["capi.hip", "reorder_quantize.hip", "direct_quantize.hip", "rmsnorm_quantize.hip", "mx_gemm.hip", "mx_gemm256.hip", "mx_gemm_skinny.hip", "qlinear_decode.hip", "diag.hip"]
-HEADERS = ["mx_common.h", "mx_kernels.h", "mx_acc_regs.h", "mx_gemm_tile.inc", "mx_gemm_tile_vgpr.inc", "mx_group_convert.h", os.path.join("..", "..", "include", "micromix_hip.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-shared", "-fgpu-rdc=0" if False else "-fno-gpu-rdc",
-         "-Wall", "-Wno-unused-function"]
+DIAG_LIB = os.path.join(LIBDIR, "libmicromix_diag.so")
+SOURCES = ["capi.hip", "reorder_quantize.hip", "direct_quantize.hip", "rmsnorm_quantize.hip", "mx_gemm.hip", "mx_gemm256.hip",
+           "mx_gemm_skinny.hip", "qlinear_decode.hip"]
+DIAG_SOURCES = ["diag.hip"]
+HEADERS = ["mx_common.h", "mx_kernels.h", "mx_acc_regs.h", "mx_gemm_tile.inc", "mx_group_convert.h",
+           os.path.join("..", "..", "include", "micromix_hip.h"), os.path.join("..", "..", "include", "micromix_diag.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 
 
 def hipcc() -> str:
     exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(exe):
-        raise RuntimeError("hipcc not found; libmicromix_hip.so cannot be built")
+        raise RuntimeError("hipcc not found; the HIP libraries cannot be built")
     return exe
 
 
-def needs_build() -> bool:
-    if not os.path.exists(LIB):
+def _newest_header() -> float:
+    return max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS + [os.path.abspath(__file__)] if os.path.exists(os.path.join(CSRC, h)))
+
+
+def _stale(target: str, deps_time: float, src: str | None = None) -> bool:
+    if not os.path.exists(target):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
-    return any(os.path.getmtime(d) > t for d in deps)
+    t = os.path.getmtime(target)
+    return t < deps_time or (src is not None and t < os.path.getmtime(src))
 
 
-def build(force: bool = False, keep_temps: bool = False, verbose: bool = True) -> str:
+def needs_build() -> bool:
+    ht = _newest_header()
+    for lib, srcs in ((LIB, SOURCES), (DIAG_LIB, DIAG_SOURCES)):
+        if _stale(lib, ht) or any(os.path.getmtime(os.path.join(CSRC, s)) > os.path.getmtime(lib) for s in srcs):
+            return True
+    return False
+
+
+def build(force: bool = False, keep_temps: bool = False, verbose: bool = True, extra_flags=()) -> str:
     if not force and not needs_build():
         return LIB
-    os.makedirs(LIBDIR, exist_ok=True)
-    cmd = [hipcc(), *FLAGS, *[os.path.join(CSRC, s) for s in SOURCES], "-o", LIB]
-    if keep_temps:
-        tmp = os.path.join(LIBDIR, "temps")
-        os.makedirs(tmp, exist_ok=True)
-        cmd += ["-save-temps=obj"]
-    if verbose:
-        print("[micromix_amd.build]", " ".join(cmd), flush=True)
-    subprocess.check_call(cmd, cwd=LIBDIR)
+    os.makedirs(OBJDIR, exist_ok=True)
+    cc, ht = hipcc(), _newest_header()
+    flags = [*FLAGS, *extra_flags] + (["-save-temps=obj"] if keep_temps else [])
+
+    def compile_one(src):
+        s, obj = os.path.join(CSRC, src), os.path.join(OBJDIR, src.replace(".hip", ".o"))
+        if force or _stale(obj, ht, s):
+            cmd = [cc, *flags, "-c", s, "-o", obj]
+            if verbose:
+                print("[micromix_amd.build]", " ".join(cmd), flush=True)
+            subprocess.check_call(cmd, cwd=OBJDIR)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
+        objs = dict(zip(SOURCES + DIAG_SOURCES, pool.map(compile_one, SOURCES + DIAG_SOURCES)))
+    for lib, srcs in ((LIB, SOURCES), (DIAG_LIB, DIAG_SOURCES)):
+        cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-fno-gpu-rdc", *[objs[s] for s in srcs], "-o", lib]
+        if verbose:
+            print("[micromix_amd.build]", " ".join(cmd), flush=True)
+        subprocess.check_call(cmd, cwd=LIBDIR)
     return LIB
 
 
 if __name__ == "__main__":
     build(force="--force" in sys.argv, keep_temps="--keep-temps" in sys.argv)
     print(LIB)
+    print(DIAG_LIB)

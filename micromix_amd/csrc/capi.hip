@@ -8,8 +8,9 @@
 
 
 static thread_local char g_last_error[256] = "";
-static hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;  // diagnostics: see mm_diag_set_kernel_events
-static unsigned long long *g_clock_buf = nullptr;  // diagnostics: see mm_diag_set_clock_buffer
+// measurement hooks, per calling thread (see mm_diag_set_kernel_events / mm_diag_set_clock_buffer in the header)
+static thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
+static thread_local unsigned long long *g_clock_buf = nullptr;
 
 static int fail_hip(hipError_t e, const char *where) {
     snprintf(g_last_error, sizeof(g_last_error), "%s: %s", where, hipGetErrorString(e));
@@ -23,7 +24,9 @@ static bool split_ok(int K, int KN, int KS, int KO) {
 
 extern "C" {
 
-int mm_version(void) { return 130; /* 0.1.3: + mm_matmul_ws, mm_rmsnorm_quantize, mm_qlinear_decode */ }
+int mm_version(void) { return 200; /* 0.2.0: diagnostics moved to libmicromix_diag.so, + mm_test_function */ }
+
+const char *mm_test_function(void) { return "Hello from test_function!"; /* bindings.cpp:700 */ }
 
 const char *mm_strerror(int status) {
     switch (status) {
@@ -166,7 +169,10 @@ int mm_matmul_ws(const uint8_t *AN, const uint8_t *BN, const uint8_t *AS, const 
     a.SFW[0] = SFBN; a.SFW[1] = SFBS; a.SFW[2] = SFBO;
     a.K[0] = KN; a.K[1] = KS; a.K[2] = KO;
     a.M = M; a.N = N;
-    a.sfx_row_tiles = M / 128 + 1;
+    // the 128-row tiles that hold scales of real rows.  The reference allocates M/128 + 1 tiles (bindings.cpp:120) and never
+    // writes the last one when M % 128 == 0; counting only the written tiles keeps every kernel's scale reads inside ANY tensor
+    // that holds the scales of its M rows, whoever allocated it.
+    a.sfx_row_tiles = (M + 127) / 128;
     a.sfw_row_tiles = (N + 127) / 128;
     a.round_per_segment = (flags & MM_ROUND_ONCE) ? 0 : 1;
     a.bias = (const uint16_t *)bias_bf16;
@@ -247,7 +253,7 @@ int mm_matmul_grouped(const mm_group *groups, int ngroups, int N, int KN, int KS
         a.SFW[0] = g.SFBN; a.SFW[1] = g.SFBS; a.SFW[2] = g.SFBO;
         a.K[0] = KN; a.K[1] = KS; a.K[2] = KO;
         a.M = g.M; a.N = N;
-        a.sfx_row_tiles = g.M / 128 + 1;
+        a.sfx_row_tiles = (g.M + 127) / 128;
         a.sfw_row_tiles = (N + 127) / 128;
         a.round_per_segment = (flags & MM_ROUND_ONCE) ? 0 : 1;
         a.bias = (const uint16_t *)g.bias_bf16;

@@ -1,8 +1,11 @@
-// Hardware diagnostics exported through the C ABI (mm_diag_*): single scaled-MFMA issue and the
+// libmicromix_diag.so (include/micromix_diag.h) -- NOT linked into the product library.
+// Hardware diagnostics exported through a C ABI (mm_diag_*): single scaled-MFMA issue and the
 // CDNA4 MX converter instructions, so that the tests can pin (a) the operand/scale/accumulator
 // register layouts the GEMM kernel relies on and (b) the oracle's element encoders against
 // AMD's own hardware implementation of the OCP MX formats.  Not on the product path.
-#include "../../include/micromix_hip.h"
+#include <hip/hip_runtime.h>
+#include "../../include/micromix_diag.h"
+#include "../../include/micromix_hip.h"   // status codes only
 #include "mx_common.h"
 
 namespace mm {

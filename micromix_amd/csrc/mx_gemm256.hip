@@ -32,9 +32,6 @@
 #ifndef MM_L2_PREFETCH
 #define MM_L2_PREFETCH 0
 #endif
-#ifndef MM_STAGING
-#define MM_STAGING 0  // 0: LDS-DMA operand pipeline, 1: VGPR-staged (see run_segment_v)
-#endif
 #ifndef MM_EPI_DIRECT
 #define MM_EPI_DIRECT 0  // 1: epilogue stores 8 bytes per lane straight from registers (no LDS transpose)
 #endif
@@ -205,13 +202,9 @@ size_t mx_gemm_workspace_bytes(int M, int N, const int K[3], bool force) {
 }
 
 template <class KernelT>
-static hipError_t launch_tile(KernelT kern, bool &attr_done, int lds_bytes, int tiles, int threads, const GemmArgs &a,
+static hipError_t launch_tile(KernelT kern, DynamicLdsOnce &attr, int lds_bytes, int tiles, int threads, const GemmArgs &a,
                               hipStream_t stream) {
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    if (hipError_t e = attr.ensure(reinterpret_cast<const void *>(kern), lds_bytes); e != hipSuccess) return e;
     if (a.ev_start != nullptr && a.ev_stop != nullptr)
         hipExtLaunchKernelGGL(kern, dim3(tiles), dim3(threads), lds_bytes, stream, a.ev_start, a.ev_stop, 0, a);
     else
@@ -220,7 +213,7 @@ static hipError_t launch_tile(KernelT kern, bool &attr_done, int lds_bytes, int 
 }
 
 hipError_t launch_mx_gemm256(const GemmArgs &a, bool w4, hipStream_t stream) {
-    static bool done[6] = {false, false, false, false, false, false};
+    static DynamicLdsOnce done[6];
     const int tn = (a.N + 255) / 256;
     const int tiles256 = ((a.M + 255) / 256) * tn, tiles128 = ((a.M + 127) / 128) * tn;
     if (a.ws != nullptr) {
@@ -237,12 +230,7 @@ hipError_t launch_mx_gemm256(const GemmArgs &a, bool w4, hipStream_t stream) {
     }
     static const int force = env_int("MICROMIX_GEMM_TILE", 0);   // kernel-developer override: 256 or 128
     static const int tail_split = env_int("MICROMIX_GEMM_TAIL", 1);
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-            cus = 256;
-    }
+    const int cus = device_cus();
     // One workgroup fits per CU, so a launch runs in rounds of `cus` tiles.  256-row tiles move the fewest L2->LDS bytes per
     // flop; a round of 128-row tiles takes ~0.62 of a round of 256-row tiles (measured).  So 128-row tiles pay exactly when
     // they still fit in ONE round (tiles128 <= cus, i.e. at most half of the CUs would get a 256-row tile): M=2048, N=4096
@@ -252,7 +240,7 @@ hipError_t launch_mx_gemm256(const GemmArgs &a, bool w4, hipStream_t stream) {
     // more (1.5x the L2->LDS bytes per flop, which does not matter while half of the chip idles): M = 1024, N = 4096.
     const int tiles64 = ((a.M + 127) / 128) * ((a.N + 127) / 128);
     if (force == 64 || (force == 0 && 2 * tiles128 <= cus && tiles64 <= cus)) {
-        static bool done64[2] = {false, false};
+        static DynamicLdsOnce done64[2];
         if (w4) return launch_tile(g64::mx_gemm256_kernel<true, false>, done64[0], g64::Lds<true>::TOTAL, tiles64, g64::NT, a, stream);
         return launch_tile(g64::mx_gemm256_kernel<false, false>, done64[1], g64::Lds<false>::TOTAL, tiles64, g64::NT, a, stream);
     }
@@ -286,12 +274,7 @@ hipError_t launch_mx_gemm256(const GemmArgs &a, bool w4, hipStream_t stream) {
 // single problem (no split-K, no tail balancing)
 hipError_t launch_mx_gemm256_grouped(GroupedTileArgs &ga, bool w4, hipStream_t stream) {
     if (ga.ngroups < 1 || ga.ngroups > MM_MAX_GROUPS) return hipErrorInvalidValue;
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-            cus = 256;
-    }
+    const int cus = device_cus();
     const int N = ga.g[0].N;
     auto tiles = [&](int bm, int bn) {
         int t = 0;
@@ -308,13 +291,9 @@ hipError_t launch_mx_gemm256_grouped(GroupedTileArgs &ga, bool w4, hipStream_t s
         ga.first_block[i + 1] = ga.first_block[i] + ((ga.g[i].M + bm - 1) / bm) * ((N + bn - 1) / bn);
     for (int i = ga.ngroups + 1; i <= MM_MAX_GROUPS; ++i) ga.first_block[i] = ga.first_block[ga.ngroups];
     const int total = ga.first_block[ga.ngroups];
-    static bool done[6] = {false, false, false, false, false, false};
-    auto go = [&](auto kern, bool &d, int lds, int threads) -> hipError_t {
-        if (!d) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            if (e != hipSuccess) return e;
-            d = true;
-        }
+    static DynamicLdsOnce done[6];
+    auto go = [&](auto kern, DynamicLdsOnce &d, int lds, int threads) -> hipError_t {
+        if (hipError_t e = d.ensure(reinterpret_cast<const void *>(kern), lds); e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, dim3(total), dim3(threads), lds, stream, ga);
         return hipGetLastError();
     };

@@ -311,12 +311,7 @@ __global__ void __launch_bounds__(NT) mx_gemm_skinny16_grouped_kernel(GroupedGem
 
 hipError_t launch_mx_gemm_skinny(const GemmArgs &a, bool w4, hipStream_t stream) {
     using namespace skinny;
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-            cus = 256;
-    }
+    const int cus = device_cus();
     const int blocks = (a.N + BN - 1) / BN;
     static const int force16 = getenv("MICROMIX_SKINNY16") ? atoi(getenv("MICROMIX_SKINNY16")) : 0;   // kernel-developer override
     if (2 * blocks <= cus || (force16 && a.M <= 16)) {   // 16 features per workgroup while 32 would leave half of the CUs idle
@@ -345,12 +340,7 @@ hipError_t launch_mx_gemm_skinny(const GemmArgs &a, bool w4, hipStream_t stream)
 hipError_t launch_mx_gemm_skinny_grouped(const GroupedGemmArgs &ga, int max_m, bool w4, hipStream_t stream) {
     using namespace skinny;
     if (ga.ngroups < 1 || ga.ngroups > MM_MAX_GROUPS || max_m < 1 || max_m > 64) return hipErrorInvalidValue;
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-            cus = 256;
-    }
+    const int cus = device_cus();
     const int N = ga.g[0].N, blocks = (N + BN - 1) / BN;
     // with G groups in one launch there are G x blocks workgroups: 16 features per workgroup while that still leaves CUs idle
     if (2 * blocks * ga.ngroups <= cus) {

@@ -3,7 +3,39 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 namespace mm {
+
+// Per-device launcher state.  One process may drive several GPUs (the reference's --multi_gpu mode places the layers of ONE
+// process on several devices, model/parallel_utils.py:135-156): a kernel's dynamic-LDS limit and the CU count belong to the
+// device that is current at the launch, so both are cached per device id, never per process.
+constexpr int MM_MAX_DEVICES = 64;
+inline int current_device() {
+    int d = 0;
+    return (hipGetDevice(&d) == hipSuccess && d >= 0 && d < MM_MAX_DEVICES) ? d : 0;
+}
+inline int device_cus() {
+    static std::atomic<int> cus[MM_MAX_DEVICES];
+    const int dev = current_device();
+    int c = cus[dev].load(std::memory_order_relaxed);
+    if (c == 0) {
+        if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c <= 0) c = 256;
+        cus[dev].store(c, std::memory_order_relaxed);
+    }
+    return c;
+}
+// raises a kernel's dynamic shared memory limit once per device (calling it twice is harmless, so no lock)
+struct DynamicLdsOnce {
+    std::atomic<bool> done[MM_MAX_DEVICES];
+    hipError_t ensure(const void *kernel, int bytes) {
+        const int dev = current_device();
+        if (done[dev].load(std::memory_order_acquire)) return hipSuccess;
+        hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e == hipSuccess) done[dev].store(true, std::memory_order_release);
+        return e;
+    }
+};
 
 struct GemmArgs {
     const uint8_t *X[3];    // activation segments  (AN, AS, AO)

@@ -363,16 +363,6 @@ static size_t decode_operand_bytes(int M, const int K[3]) {   // quantized rows 
     return (size_t)M * (K[0] / 2 + K[1] / 4 * 3 + K[2] + Kt / 32);
 }
 
-static int device_cus() {
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-            cus = 256;
-    }
-    return cus;
-}
-
 // features per workgroup: 16 while 32 would leave half of the CUs without a workgroup
 static int decode_features(int N) { return 2 * ((N + 31) / 32) <= device_cus() ? 16 : 32; }
 
@@ -414,13 +404,9 @@ hipError_t launch_qlinear_decode(const void *X, const int16_t *idx, const uint8_
     const bool f16 = decode_features(N) == 16;
     auto kern = f16 ? (w4 ? qlinear_decode16_kernel<true> : qlinear_decode16_kernel<false>)
                     : (w4 ? qlinear_decode_kernel<true> : qlinear_decode_kernel<false>);
-    static bool done[4] = {false, false, false, false};
-    bool &d = done[(f16 ? 2 : 0) + (w4 ? 0 : 1)];
-    if (!d) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DECODE_LDS_MAX);
-        if (e != hipSuccess) return e;
-        d = true;
-    }
+    static DynamicLdsOnce done[4];
+    if (hipError_t e = done[(f16 ? 2 : 0) + (w4 ? 0 : 1)].ensure(reinterpret_cast<const void *>(kern), (int)DECODE_LDS_MAX); e != hipSuccess)
+        return e;
     const int feat = f16 ? BN16 : BN;
     hipLaunchKernelGGL(kern, dim3((N + feat - 1) / feat), dim3(NT), lds, stream, a);
     return hipGetLastError();

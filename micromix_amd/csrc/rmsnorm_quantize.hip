@@ -197,12 +197,17 @@ hipError_t launch_rmsnorm_quantize(const void *src, const void *weight, float ep
     auto kern = threads <= 256 ? (integer_round ? rmsnorm_quantize_kernel<true, 256> : rmsnorm_quantize_kernel<false, 256>)
               : threads <= 512 ? (integer_round ? rmsnorm_quantize_kernel<true, 512> : rmsnorm_quantize_kernel<false, 512>)
                                : (integer_round ? rmsnorm_quantize_kernel<true, 1024> : rmsnorm_quantize_kernel<false, 1024>);
+    // K = 32768: 64 KiB of row + 4 KiB of partial sums, above the default 64 KiB limit of dynamic LDS
+    static DynamicLdsOnce attr[6];
+    if (lds > 48 * 1024) {
+        const int which = (threads <= 256 ? 0 : threads <= 512 ? 1 : 2) * 2 + (integer_round ? 1 : 0);
+        if (hipError_t e = attr[which].ensure(reinterpret_cast<const void *>(kern), 72 * 1024); e != hipSuccess) return e;
+    }
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kern), threads, lds) != hipSuccess ||
         per_cu < 1)
         per_cu = 1;
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int cus = device_cus();
     int blocks = cus * per_cu;
     blocks = rows < blocks ? rows : blocks;
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds, stream, (const uint16_t *)src, (const uint16_t *)weight, eps, rows,

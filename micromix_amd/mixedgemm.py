@@ -27,8 +27,13 @@ import torch
 
 from . import _lib
 
-__all__ = ["matmul", "reorder_quantize_x", "reorder_quantize_w", "reorder_quantize_w4", "activate_quantize_x",
+__all__ = ["test_function", "matmul", "reorder_quantize_x", "reorder_quantize_w", "reorder_quantize_w4", "activate_quantize_x",
            "downproj_quantize_w", "downproj_quantize_w4", "rmsnorm_quantize_x", "qlinear_decode", "qlinear_decode_supported", "matmul_grouped", "reorder_quantize_x_grouped"]
+
+
+def test_function():
+    """bindings.cpp:700: the module's liveness probe (answered by the HIP library, so it also proves the library loads)."""
+    return _lib.load().mm_test_function().decode()
 
 
 def _stream_ptr(device) -> int:
@@ -198,6 +203,12 @@ def matmul(AN, BN, AS, BS, AO, BO, SFAN, SFBN, SFAS, SFBS, SFAO, SFBO, *, bias=N
             _check_tensor(out, "out", torch.bfloat16, dev)
         if out.dim() != 2 or out.size(0) != M or out.size(1) != N:
             raise RuntimeError("out has the wrong shape")
+    # the kernels move operands in 16-byte pieces (LDS-DMA, dwordx4 loads): views at odd offsets are rejected, not mis-read
+    for t in tensors:
+        if t.data_ptr() & 15 and t.numel():
+            raise RuntimeError("matmul operands must be 16-byte aligned (got a view at an unaligned offset)")
+    if out.data_ptr() & 15:
+        raise RuntimeError("out must be 16-byte aligned")
     # shapes with few output tiles split K and need scratch for fp32 partial sums; it comes from torch's caching allocator
     # (stream-ordered, graph-capture safe) because the C ABI never allocates
     ws, ws_bytes = None, 0

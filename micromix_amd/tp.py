@@ -9,7 +9,17 @@ slice of the *reordered* columns.  It
   3. runs the fused three-segment GEMM on its shard -> partial [M, N] bf16,
   4. sums the partials with ONE all-reduce on the bf16 output (RCCL over xGMI; `nccl` backend).
 Because MX blocks are 32 columns and shards are 128-aligned, every block keeps exactly the scale it has
-in the unsharded layer: the sharded product is the unsharded one up to the order of the final sums.
+in the unsharded layer.  Each rank runs its shard with ONE bf16 rounding (`SHARD_ROUNDING = "fused"`: a rank's
+three segments are partial sums of the same output, rounding between them would only add error) and the
+all-reduce adds the `world` rounded partials in bf16, so the result differs from the unsharded fused product by
+at most ~world bf16 half-ulps of the largest partial (not bit-equal: tests/test_tp_gpu.py states the bound).
+
+Two more layouts live here because section 8e asks for them next to the K-shard:
+  * `ColumnParallelLinear` (N-shard): rank g owns a 128-aligned set of OUTPUT features, full K, no reduction; the
+    local [M, N_g] slice is what the next row-parallel layer consumes (or `all_gather`s into [M, N]);
+  * `TPMLP` (Megatron pairing): gate/up column-parallel over the intermediate features that the rank's down_proj
+    K-shard consumes -> silu(gate)*up + quantize on the LOCAL slice (`activate_quantize_x`) -> down_proj
+    row-parallel -> ONE all-reduce of [M, hidden] per MLP instead of three.
 
 Shards are balanced by COST, not width: an fp8-operand column costs ~1.67x an fp4 column on the MFMA
 (measured issue rates, tools/mfma_rate.py), so each rank gets a share of every segment.
@@ -25,6 +35,8 @@ import torch
 
 # relative MFMA cost per column of (fp4, fp6, fp8) activations against fp4 weights (w4 mode)
 SEGMENT_COST = (1.0, 1.07, 1.67)
+# rounding mode of a rank's partial product (see the module docstring)
+SHARD_ROUNDING = "fused"
 
 
 def plan_k_shards(kn: int, ks: int, ko: int, world: int) -> List[Tuple[Tuple[int, int], Tuple[int, int], Tuple[int, int]]]:
@@ -80,9 +92,19 @@ class _HipOps:
         return mixedgemm._quantize(x, index, kn, ks, ko, "x", "reorder_quantize_x", gather_subset=True)
 
     @staticmethod
-    def matmul(a, b, out=None):
+    def matmul(a, b, out=None, rounding=SHARD_ROUNDING):
         from . import mixedgemm
-        return mixedgemm.matmul(a[0], b[0], a[1], b[1], a[2], b[2], a[3], b[3], a[4], b[4], a[5], b[5], out=out)
+        return mixedgemm.matmul(a[0], b[0], a[1], b[1], a[2], b[2], a[3], b[3], a[4], b[4], a[5], b[5], out=out, rounding=rounding)
+
+    @staticmethod
+    def activate_quantize(a, b, kn, ks, ko):
+        from . import mixedgemm
+        return mixedgemm.activate_quantize_x(a, b, kn, ks, ko)
+
+    @staticmethod
+    def downproj_quantize_w4(w, kn, ks, ko):
+        from . import mixedgemm
+        return mixedgemm.downproj_quantize_w4(w, kn, ks, ko)
 
 
 class TPShardedLinear:
@@ -156,5 +178,127 @@ class TPShardedLinear:
         out = torch.empty((x2.shape[0], self.N), dtype=torch.bfloat16, device=x2.device)
         y = self.matmul_allreduce(self.quantize_x(x2), out=out)
         return y.reshape(*lead, self.N)
+
+    __call__ = forward
+
+
+def shard_positions(kn: int, ks: int, ko: int, shard) -> torch.Tensor:
+    """positions (in the reordered column order fp4 | fp6 | fp8) that a K-shard owns: its slice of each segment, concatenated"""
+    seg_base = (0, kn, kn + ks)
+    return torch.cat([torch.arange(seg_base[s] + shard[s][0], seg_base[s] + shard[s][0] + shard[s][1]) for s in range(3)])
+
+
+class ColumnParallelLinear:
+    """One QLinear, N-sharded: this rank owns the output features `features` (a LongTensor, or None for an even 128-aligned
+    split of range(N)), the full K and the full reorder index.  forward(x) -> the local [M, N_g] slice in the reference's
+    rounding (this is a complete product, not a partial sum); `gather_output=True` all-gathers [M, N] (equal shard sizes only)."""
+
+    def __init__(self, w: torch.Tensor, reorder_index: torch.Tensor, p4: int, p6: int, p8: int, rank: int, world: int,
+                 group=None, ops=None, bias: torch.Tensor | None = None, features: torch.Tensor | None = None,
+                 gather_output: bool = False):
+        self.rank, self.world, self.group = rank, world, group
+        self.ops = ops if ops is not None else _HipOps
+        self.N, self.K = w.shape
+        self.split = (p4, p6, p8)
+        if p4 + p6 + p8 != self.K:
+            raise ValueError("p4 + p6 + p8 must equal in_features")
+        if features is None:
+            gran = (self.N + 127) // 128
+            base, rem = divmod(gran, world)
+            g0 = rank * base + min(rank, rem)
+            g1 = g0 + base + (1 if rank < rem else 0)
+            features = torch.arange(min(g0 * 128, self.N), min(g1 * 128, self.N))
+        self.features = features
+        self.index = reorder_index.to(torch.int16).contiguous()
+        self.empty = features.numel() == 0
+        self.gather_output = gather_output
+        self.bias = bias[features.to(bias.device)] if bias is not None else None
+        if not self.empty:
+            self.packed_w = self.ops.quantize_w4(w[features.to(w.device)].contiguous(), self.index, p4, p6, p8)
+
+    def quantize_x(self, x: torch.Tensor):
+        return self.ops.quantize_x(x, self.index, *self.split)
+
+    def matmul(self, qx):
+        y = self.ops.matmul(qx, self.packed_w, rounding="reference")
+        if self.bias is not None:
+            y = y + self.bias
+        return y
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        import torch.distributed as dist
+        lead = x.shape[:-1]
+        y = self.matmul(self.quantize_x(x.reshape(-1, self.K).contiguous()))
+        if self.gather_output and self.world > 1:
+            parts = [torch.empty_like(y) for _ in range(self.world)]
+            dist.all_gather(parts, y, group=self.group)
+            y = torch.cat(parts, dim=1)
+        return y.reshape(*lead, y.shape[-1])
+
+    __call__ = forward
+
+
+class TPMLP:
+    """gate/up/down of one decoder MLP (qLlamaLayer.py:336-387) with ONE all-reduce (Megatron pairing).
+
+    Inputs are the FULL tensors: w_gate, w_up [I, H] whose rows are already in the down_proj's reordered order and w_down
+    [H, I] whose columns are in that same order -- the reference folds the down_proj reorder into the gate/up output order
+    (`out_reorder_index`, qLlamaLayer.py:341,354) and packs the down weight with `downproj_quantize_w4` in natural column
+    order (bindings.cpp:363-387); `in_index` / `in_split` = reorder index and (p4, p6, p8) of the hidden input of gate/up,
+    `down_split` = (p4, p6, p8) of the intermediate features.
+
+    Rank g takes the K-shard plan of the down_proj (`plan_k_shards(*down_split)`), i.e. 128-aligned slices of the fp4 / fp6 / fp8
+    ranges of the intermediate features; its gate/up shards are exactly those rows.  Then
+        qx = quantize(x)                      full hidden input, replicated (or shared with the caller through `quantize_x`)
+        g, u = gate_g(qx), up_g(qx)           column-parallel: [M, I_g], complete products, no communication
+        qh = activate_quantize_x(g, u, ...)   silu(g) * u -> mixed quantize of the LOCAL slice; every 32-block and its scale are
+                                              the ones the unsharded layer computes, because shards are 128-aligned
+        part = down_g(qh)                     row-parallel partial [M, H], one bf16 rounding
+        y = all_reduce(part)                  the only collective: M * H * 2 bytes
+    """
+
+    def __init__(self, w_gate: torch.Tensor, w_up: torch.Tensor, w_down: torch.Tensor, in_index: torch.Tensor, in_split,
+                 down_split, rank: int, world: int, group=None, ops=None):
+        self.rank, self.world, self.group = rank, world, group
+        self.ops = ops if ops is not None else _HipOps
+        self.I, self.H = w_gate.shape
+        if tuple(w_up.shape) != (self.I, self.H) or tuple(w_down.shape) != (self.H, self.I):
+            raise ValueError("expected w_gate, w_up [I, H] and w_down [H, I]")
+        if sum(in_split) != self.H or sum(down_split) != self.I:
+            raise ValueError("in_split must sum to the hidden size and down_split to the intermediate size")
+        self.in_split = tuple(in_split)
+        self.in_index = in_index.to(torch.int16).contiguous()
+        self.shard = plan_k_shards(*down_split, world)[rank]
+        self.widths = tuple(s[1] for s in self.shard)
+        self.positions = shard_positions(*down_split, self.shard)
+        self.empty = self.positions.numel() == 0
+        if not self.empty:
+            sel = self.positions.to(w_gate.device)
+            self.packed_gate = self.ops.quantize_w4(w_gate[sel].contiguous(), self.in_index, *self.in_split)
+            self.packed_up = self.ops.quantize_w4(w_up[sel].contiguous(), self.in_index, *self.in_split)
+            self.packed_down = self.ops.downproj_quantize_w4(w_down[:, sel].contiguous(), *self.widths)
+
+    def quantize_x(self, x2d: torch.Tensor):
+        return self.ops.quantize_x(x2d, self.in_index, *self.in_split)
+
+    def partial(self, qx) -> torch.Tensor | None:
+        """this rank's [M, H] partial of the MLP output (None for an empty shard)"""
+        if self.empty:
+            return None
+        g = self.ops.matmul(qx, self.packed_gate, rounding="reference")
+        u = self.ops.matmul(qx, self.packed_up, rounding="reference")
+        qh = self.ops.activate_quantize(g, u, *self.widths)
+        return self.ops.matmul(qh, self.packed_down)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        import torch.distributed as dist
+        lead = x.shape[:-1]
+        x2 = x.reshape(-1, self.H).contiguous()
+        part = self.partial(self.quantize_x(x2))
+        if part is None:
+            part = torch.zeros((x2.shape[0], self.H), dtype=torch.bfloat16, device=x2.device)
+        if self.world > 1:
+            dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.group)
+        return part.reshape(*lead, self.H)
 
     __call__ = forward

@@ -461,14 +461,28 @@ def matmul_shapes(an, bn, a_s, bs, ao, bo):
     return m, n, kn, ks, ko, ("w" if same else "w4")
 
 
+def dequant_operand(q, kind: str, wmode: str = "w"):
+    """the three segments of a packed operand (as returned by reorder_quantize) as fp64 [rows, Kseg] arrays (None
+    for an empty segment).  kind "x": formats (fp4, fp6, fp8); kind "w": the same unless wmode == "w4" (all fp4)."""
+    fmts = ("fp4", "fp4", "fp4") if (kind == "w" and wmode == "w4") else ("fp4", "fp6", "fp8")
+    rows = q[0].shape[0]
+    out = []
+    for i, fmt in enumerate(fmts):
+        kseg = q[i].shape[1] * 8 // FORMATS[fmt]["bits"]
+        out.append(dequant_segment(q[i], q[3 + i], rows, kseg, fmt, np.float64) if kseg else None)
+    return out
+
+
 def matmul(an, bn, a_s, bs, ao, bo, sfan, sfbn, sfas, sfbs, sfao, sfbo,
-           rounding: str = "reference", return_f64: bool = False):
+           rounding: str = "reference", return_f64: bool = False, b_dequant=None, return_parts: bool = False):
     """Three-segment mixed-MX GEMM -> bf16 bits [M, N].
 
     rounding="reference": D = bf16(acc_N); D = bf16(acc_S + D); D = bf16(acc_O + D)
                           (gemm.cu:48-50 / 75-77: each segment is its own kernel
                           and D round-trips through bf16).
     rounding="fused":     D = bf16(acc_N + acc_S + acc_O), one rounding.
+    b_dequant: optional `dequant_operand(B, "w", wmode)` computed earlier (tests that reuse one weight for many
+    activations); return_parts: also return the per-segment fp64 products and the dequantised operands.
     """
     m, n, kn, ks, ko, wmode = matmul_shapes(an, bn, a_s, bs, ao, bo)
     bf = ("fp4", "fp4", "fp4") if wmode == "w4" else ("fp4", "fp6", "fp8")
@@ -476,19 +490,24 @@ def matmul(an, bn, a_s, bs, ao, bo, sfan, sfbn, sfas, sfbs, sfao, sfbo,
     segs = [(an, bn, sfan, sfbn, kn), (a_s, bs, sfas, sfbs, ks), (ao, bo, sfao, sfbo, ko)]
     d = np.zeros((m, n), dtype=np.float32)              # C = torch::zeros (bindings.cpp:72)
     total64 = np.zeros((m, n), dtype=np.float64)
-    for (a, b, sfa, sfb, kseg), fa, fb in zip(segs, af, bf):
+    parts = []
+    for i, ((a, b, sfa, sfb, kseg), fa, fb) in enumerate(zip(segs, af, bf)):
         if kseg == 0:
             continue
         a64 = dequant_segment(a, sfa, m, kseg, fa, np.float64)
-        b64 = dequant_segment(b, sfb, n, kseg, fb, np.float64)
+        b64 = b_dequant[i] if b_dequant is not None else dequant_segment(b, sfb, n, kseg, fb, np.float64)
         acc64 = a64 @ b64.T
         total64 += acc64
+        if return_parts:
+            parts.append((acc64, a64, b64))
         if rounding == "reference":
             acc = acc64.astype(np.float32)               # fp32 accumulator (w4a4.cu:27)
             d = bf16_to_f32(f32_to_bf16(acc + d))
     if rounding == "fused":
         d = bf16_to_f32(f32_to_bf16(total64.astype(np.float32)))
     out = f32_to_bf16(d)
+    if return_parts:
+        return out, parts
     return (out, total64) if return_f64 else out
 
 

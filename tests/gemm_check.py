@@ -20,35 +20,42 @@ from oracle import mx_oracle as o
 EPS_HW = 2.0 ** -11
 
 
-def abs_dot_and_partials(qx, qw):
-    """returns (S [M,N] float64, list of fp64 per-segment products)."""
-    m, n, kn, ks, ko, wmode = o.matmul_shapes(qx[0], qw[0], qx[1], qw[1], qx[2], qw[2])
-    af = ("fp4", "fp6", "fp8")
-    bf = ("fp4", "fp4", "fp4") if wmode == "w4" else af
-    S = np.zeros((m, n))
-    parts = []
-    for i, kseg in enumerate((kn, ks, ko)):
-        if not kseg:
-            continue
-        a = o.dequant_segment(qx[i], qx[3 + i], m, kseg, af[i], np.float64)
-        b = o.dequant_segment(qw[i], qw[3 + i], n, kseg, bf[i], np.float64)
+# Statistics asserted with `strict=True` (SURVEY.md section 8c proposed "<= 1 bf16 ulp on >= 99.9 % of the elements,
+# <= 2 ulp max" against the reference CUDA kernel; against a CPU oracle that sums in fp64 they read as follows):
+#   * frac_gt1 <= 1e-3: at most 0.1 % of the outputs differ from the oracle by more than one bf16 ulp;
+#   * frac_exact >= FRAC_EXACT[mode]: the share of bit-equal outputs.  With fp4 weights ("w4", the production mode) fp4 x fp4 and
+#     fp6 x fp4 blocks are summed exactly by the MFMA and only the fp8 x fp4 block sums carry the adder-tree error; with
+#     matching-precision weights ("w") the fp6 x fp6 and fp8 x fp8 block sums carry ~1e-4 * S of error, which moves a result
+#     across a rounding boundary more often -- hence the lower bar for "w";
+#   * max_ulp <= 2 over the outputs that are not cancellation results (|want| >= 2^-4 * S / sqrt(K-blocks) would be the natural
+#     scale; implemented as |want| >= CANCEL * S).  An output far smaller than the sum of its terms' magnitudes has few
+#     significant bits left in ANY summation order, so its ulp distance is unbounded by construction; those outputs are held
+#     to the absolute bound above instead.
+FRAC_EXACT = {"w4": 0.99, "w": 0.97}
+CANCEL = 2.0 ** -9
+
+
+def check_gemm(got_bits, qx, qw, rounding="reference", eps=EPS_HW, label="", strict=False, wdeq=None, bias_bits=None):
+    """asserts the tolerance above (and the statistics, with strict=True); returns a dict of statistics.
+    wdeq: cached o.dequant_operand(qw, "w", wmode); bias_bits: [N] bf16 bits added the reference's way (qLinearLayer.py:70-71:
+    y = bf16(y + bias)) to the oracle result before the comparison."""
+    wmode = o.matmul_shapes(qx[0], qw[0], qx[1], qw[1], qx[2], qw[2])[5]
+    want, segs = o.matmul(qx[0], qw[0], qx[1], qw[1], qx[2], qw[2], qx[3], qw[3], qx[4], qw[4], qx[5], qw[5], rounding=rounding,
+                          b_dequant=wdeq, return_parts=True)
+    S = np.zeros(want.shape)
+    run = np.zeros(want.shape)
+    rounding_budget = np.zeros(want.shape)
+    for p, a, b in segs:
         S += np.abs(a) @ np.abs(b).T
-        parts.append(a @ b.T)
-    return S, parts
-
-
-def check_gemm(got_bits, qx, qw, rounding="reference", eps=EPS_HW, label=""):
-    """asserts the tolerance above; returns a dict of statistics."""
-    want = o.matmul(qx[0], qw[0], qx[1], qw[1], qx[2], qw[2], qx[3], qw[3], qx[4], qw[4], qx[5], qw[5], rounding=rounding)
-    S, parts = abs_dot_and_partials(qx, qw)
-    run = np.zeros_like(S)
-    rounding_budget = np.zeros_like(S)
-    if rounding == "reference":
-        for p in parts:
-            run = run + p
+        run = run + p
+        if rounding == "reference":
             rounding_budget += np.abs(run)
-    else:
-        rounding_budget = np.abs(sum(parts)) if parts else rounding_budget
+    if rounding != "reference":
+        rounding_budget = np.abs(run)
+    if bias_bits is not None:
+        bias = o.bf16_to_f32(np.asarray(bias_bits)).astype(np.float64)[None, :]
+        want = o.f32_to_bf16(o.bf16_to_f32(want) + bias.astype(np.float32))
+        rounding_budget = rounding_budget + np.abs(run + bias)
     g = o.bf16_to_f32(got_bits).astype(np.float64)
     w = o.bf16_to_f32(want).astype(np.float64)
     finite = np.isfinite(w) & np.isfinite(S)
@@ -56,8 +63,13 @@ def check_gemm(got_bits, qx, qw, rounding="reference", eps=EPS_HW, label=""):
     err = np.abs(g - w)
     bad = finite & ~(err <= tol)
     ulp = o.bf16_ulp_distance(got_bits, want)
+    big = finite & (np.abs(w) >= CANCEL * S)
     stats = dict(max_ulp=int(ulp[finite].max()) if finite.any() else 0, frac_exact=float((ulp[finite] == 0).mean()),
                  frac_gt1=float((ulp[finite] > 1).mean()), worst_ratio=float((err[finite] / tol[finite]).max()),
+                 max_ulp_noncancelling=int(ulp[big].max()) if big.any() else 0,
                  hw_eps=float((np.maximum(err - 2.0 ** -8 * np.abs(w), 0)[finite] / (S[finite] + 1e-300)).max()))
     assert not bad.any(), f"{label}: {int(bad.sum())} elements outside tolerance; stats {stats}"
+    if strict:
+        assert stats["frac_gt1"] <= 1e-3 and stats["frac_exact"] >= FRAC_EXACT[wmode] and stats["max_ulp_noncancelling"] <= 2, \
+            f"{label}: ulp statistics {stats}"
     return stats

@@ -19,7 +19,7 @@ from oracle import mx_oracle as o  # noqa: E402
 import hw_layout as hl  # noqa: E402
 from conftest import t_from_bits, bits_from_t, u8, make_inputs  # noqa: E402
 
-lib = _lib.load()
+lib = _lib.load_diag()
 dev = torch.device("cuda:0")
 rng = np.random.default_rng(0)
 

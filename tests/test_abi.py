@@ -16,8 +16,8 @@ from oracle import mx_oracle as o
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def header_functions():
-    text = open(os.path.join(ROOT, "include", "micromix_hip.h")).read()
+def header_functions(name="micromix_hip.h"):
+    text = open(os.path.join(ROOT, "include", name)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(mm_[a-z0-9_]+)\s*\(", text)))
 
@@ -28,7 +28,18 @@ def test_library_exports_every_declared_symbol():
     assert declared and set(declared) == set(_lib.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.mm_version() >= 100
+    assert lib.mm_version() >= 200
+    assert mixedgemm.test_function() == "Hello from test_function!"        # bindings.cpp:700
+
+
+def test_diag_library_is_separate_from_the_product_library():
+    """the hardware probes / microbenchmarks live in libmicromix_diag.so; the product library exports none of them"""
+    diag = _lib.load_diag()
+    declared = header_functions("micromix_diag.h")
+    assert declared and set(declared) == set(_lib.DIAG_EXPORTS)
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(diag, name) and not hasattr(lib, name), name
 
 
 def test_host_helpers_match_oracle():

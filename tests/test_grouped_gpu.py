@@ -1,6 +1,9 @@
-"""GPU test of the grouped GEMM (MoE expert batching): bit-identical to one matmul per group."""
+"""GPU test of the grouped GEMM (MoE expert batching): every group against the oracle, and
+bit-identical to one matmul per group.  (Full Mixtral expert shapes: tests/test_model_shapes_gpu.py.)"""
 import pytest
 
+from conftest import bits_from_t, u8
+from gemm_check import check_gemm
 from micromix_amd import mixedgemm
 
 pytestmark = pytest.mark.gpu
@@ -38,6 +41,9 @@ def test_grouped_equals_per_group_matmul(dev, wmode, n, k, split, ms):
         assert len(got) == len(ms)
         for i, (y, ref) in enumerate(zip(got, want)):
             assert y.shape == ref.shape and torch.equal(y, ref), (i, ms[i], rounding)
+            if ms[i]:      # the oracle on the same packed operands (quantizer parity: tests/test_quantize_gpu.py)
+                check_gemm(bits_from_t(y), [u8(t) for t in As[i]], [u8(t) for t in Bs[i]], rounding, label=f"group {i} M={ms[i]} {rounding}",
+                           bias_bits=bits_from_t(biases[i]) if biases[i] is not None else None)
 
 
 def test_grouped_argument_checks(dev):

@@ -244,3 +244,45 @@ def test_errors(dev):
         mixedgemm.matmul(z(4, 64), z(8, 64), z(4, 0), z(8, 0), z(4, 0), z(8, 0), z(4), z(512), z(0), z(0), z(0), z(0))
     d = mixedgemm.matmul(z(4, 0), z(8, 0), z(4, 0), z(8, 0), z(4, 0), z(8, 0), z(0), z(0), z(0), z(0), z(0), z(0))
     assert d.shape == (4, 8) and float(d.abs().sum()) == 0.0                 # K == 0 -> zeros (bindings.cpp:72)
+
+
+def test_minimal_scale_tensors_and_alignment(dev):
+    """activation scale tensors of the minimal size ceil(M/128) row tiles (the reference allocates M/128 + 1, bindings.cpp:120)
+    are enough for every kernel, also when M % 256 == 128 (second half of a 256-row tile absent); unaligned views are rejected"""
+    import torch
+    rng = np.random.default_rng(31)
+    for m, n, k, split in ((128, 512, 512, (256, 128, 128)), (384, 2048, 256, (128, 0, 128)), (1152, 4096, 256, (0, 0, 256))):
+        qx, qw = quantized(rng, m, n, k, split, "w4")
+        widths = split
+        small = list(qx[:3]) + [sf[: (m + 127) // 128 * 128 * (w // 32)].copy() for sf, w in zip(qx[3:], widths)]
+        a, b = to_dev(dev, small), to_dev(dev, qw)
+        # place each minimal scale tensor at the very end of its own allocation-sized buffer region: a read past it would
+        # leave the tensor (caught by the checker below only through wrong results, so compare with the full-size run)
+        full = gpu_matmul(dev, qx, qw)
+        got = bits_from_t(mixedgemm.matmul(a[0], b[0], a[1], b[1], a[2], b[2], a[3], b[3], a[4], b[4], a[5], b[5]))
+        assert np.array_equal(got, full)
+        check_gemm(got, qx, qw, "reference", label=f"minimal SF {m}x{n}x{k}")
+    z = lambda *s: torch.zeros(s, dtype=torch.uint8, device=dev)
+    big = z(4, 64 + 16)
+    with pytest.raises(RuntimeError, match="16-byte aligned"):
+        mixedgemm.matmul(big.view(-1)[1:257].view(4, 64), z(8, 64), z(4, 0), z(8, 0), z(4, 0), z(8, 0), z(512), z(512), z(0), z(0), z(0), z(0))
+
+
+def test_two_devices_in_one_process(dev):
+    """the reference's --multi_gpu mode (parallel_utils.py:135-156) places layers of ONE process on several devices: every
+    device gets its own dynamic-LDS attribute and CU count (the launchers cache both per device id)"""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs in one process")
+    rng = np.random.default_rng(41)
+    qx, qw = quantized(rng, 300, 512, 1024, (512, 128, 384), "w4")
+    outs = []
+    for d in (1, 0, 1):
+        dd = torch.device("cuda", d)
+        outs.append(gpu_matmul(dd, qx, qw))
+        x = t_from_bits(make_inputs(rng, 4, 1024), dd)          # decode + quantizer launchers on that device too
+        idx = torch.arange(1024, dtype=torch.int16, device=dd)
+        mixedgemm.rmsnorm_quantize_x(x, x[0].contiguous(), 1e-5, idx, 512, 128, 384)
+        torch.cuda.synchronize(dd)
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    check_gemm(outs[0], qx, qw, "reference", label="two devices")

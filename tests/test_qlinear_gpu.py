@@ -48,8 +48,15 @@ def test_prequantized_tuple_input(dev):
         layers.append(QLinearLayer(lin.to(dev), p8_num=split[2], p6_num=split[1], reorder_index=idx))
     shared = layers[0].quantize_input(x)
     assert len(shared) == 8 and shared[6:] == (2, 9)
+    from conftest import u8
+    from gemm_check import check_gemm
+    ref_q = o.reorder_quantize(bits_from_t(x.reshape(18, k)), u8(layers[0].reorder_index), *split, "x")
     for q in layers:
-        assert torch.equal(q(shared), q(x))
+        y = q(shared)
+        assert torch.equal(y, q(x))
+        # against the oracle: quantize-x of the same input, the layer's packed weight, reference rounding
+        check_gemm(bits_from_t(y.reshape(18, -1)), ref_q, [u8(t) for t in (q.BN, q.BS, q.BO, q.SFBN, q.SFBS, q.SFBO)], "reference",
+                   label="tuple input", strict=True)
     with pytest.raises(RuntimeError, match="different"):
         QLinearLayer(torch.nn.Linear(k, 128, bias=False, dtype=torch.bfloat16).to(dev), p8_num=256, p6_num=128, reorder_index=idx)(shared)
 
@@ -94,6 +101,10 @@ def test_expert_style_tuple_with_bsz_none(dev):
     q = mixedgemm.reorder_quantize_x(x, layer.reorder_index, *split)
     y = layer((*q, None, 37))
     assert y.shape == (37, 256) and torch.equal(y, layer(x.unsqueeze(0))[0])
+    from conftest import u8
+    from gemm_check import check_gemm
+    check_gemm(bits_from_t(y), o.reorder_quantize(bits_from_t(x), u8(layer.reorder_index), *split, "x"),
+               [u8(t) for t in (layer.BN, layer.BS, layer.BO, layer.SFBN, layer.SFBS, layer.SFBO)], "reference", label="expert tuple", strict=True)
 
 
 def test_call_plan_follows_replaced_weights(dev):

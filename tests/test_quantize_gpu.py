@@ -43,6 +43,7 @@ CASES = [
     (257, 3072, (1024, 1024, 1024)), (64, 3584, (3584, 0, 0)),
     (40, 5120, (4096, 512, 512)), (24, 8192, (0, 0, 8192)), (17, 11008 + 128, (10112, 896, 128)),
     (9, 13824, (12288, 1024, 512)), (16, 14336, (7168, 512, 6656)), (5, 18944, (12544, 3200, 3200)),
+    (3, 32768, (16384, 8192, 8192)),                                            # the largest K the int16 index allows (64 KiB of LDS)
 ]
 
 

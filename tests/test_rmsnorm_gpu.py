@@ -26,7 +26,8 @@ def check_exact(got, want, rows, split, label):
 
 CASES = [(1, 128, (0, 128, 0)), (3, 384, (128, 128, 128)), (130, 4096, (2048, 1024, 1024)), (64, 4096, (0, 0, 4096)),
          (17, 5120, (4096, 512, 512)), (9, 3072, (1024, 1024, 1024)), (5, 3584, (3584, 0, 0)), (2, 14336, (7168, 512, 6656)),
-         (3, 20480, (8192, 4096, 8192))]      # K > 16384: the 1024-thread variant
+         (3, 20480, (8192, 4096, 8192)),      # K > 16384: the 1024-thread variant
+         (3, 32768, (16384, 8192, 8192))]     # the largest K the int16 reorder index allows: 68 KiB of dynamic LDS
 
 
 @pytest.mark.parametrize("integer_round", (True, False))

@@ -57,13 +57,21 @@ class OracleOps:
         return o.reorder_quantize(cls._bits(x), index.numpy(), kn, ks, ko, "x", gather_subset=True)
 
     @staticmethod
-    def matmul(a, b, out=None):
-        d = o.matmul(a[0], b[0], a[1], b[1], a[2], b[2], a[3], b[3], a[4], b[4], a[5], b[5])
+    def matmul(a, b, out=None, rounding=tp.SHARD_ROUNDING):
+        d = o.matmul(a[0], b[0], a[1], b[1], a[2], b[2], a[3], b[3], a[4], b[4], a[5], b[5], rounding=rounding)
         t = torch.from_numpy(d.view(np.int16).copy()).view(torch.bfloat16)
         if out is not None:
             out.copy_(t)
             return out
         return t
+
+    @classmethod
+    def activate_quantize(cls, a, b, kn, ks, ko):
+        return o.activate_quantize(cls._bits(a), cls._bits(b), kn, ks, ko)
+
+    @classmethod
+    def downproj_quantize_w4(cls, w, kn, ks, ko):
+        return o.downproj_quantize(cls._bits(w), kn, ks, ko, True)
 
 
 def _inputs():
@@ -104,8 +112,8 @@ def test_two_rank_gloo_matches_unsharded_oracle():
     assert np.array_equal(res[0][1], res[1][1])                       # all-reduce: every rank holds the sum
     assert [sum(wd) for wd in zip(res[0][0], res[1][0])] == list(split)
     got = res[0][1].astype(np.float64)
-    # each rank rounds its partial (3 segment roundings) to bf16, the all-reduce adds them in bf16: a few ulps of the
-    # partial magnitudes.  |partials| <= S, the absolute dot product.
+    # each rank rounds its partial to bf16 once (tp.SHARD_ROUNDING), the all-reduce adds the two in bf16: three roundings of
+    # values bounded by the partial magnitudes.  |partials| <= S, the absolute dot product.
     a = [o.dequant_segment(qx[i], qx[3 + i], m, split[i], f) for i, f in enumerate(("fp4", "fp6", "fp8"))]
     b = [o.dequant_segment(qw[i], qw[3 + i], n, split[i], "fp4") for i in range(3)]
     S = sum(np.abs(ai).astype(np.float64) @ np.abs(bi).astype(np.float64).T for ai, bi in zip(a, b))
@@ -138,3 +146,73 @@ def test_chunked_async_allreduce_equals_single_allreduce():
         ret = mgr.dict()
         mp.spawn(_worker_chunked, args=(world, port, ret), nprocs=world, join=True)
         assert dict(ret) == {0: True, 1: True}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# column-parallel (N-shard) layer and the Megatron MLP pairing ("cheaper alternative")
+# ---------------------------------------------------------------------------------------------------------------------
+def _mlp_inputs():
+    m, h, inter = 20, 256, 1024
+    in_split, down_split = (128, 0, 128), (512, 128, 384)
+    tb = lambda bits: torch.from_numpy(bits.view(np.int16).copy()).view(torch.bfloat16)
+    x = tb(lcg.bf16_normalish(21, (m, h)))
+    wg = tb(lcg.bf16_normalish(22, (inter, h), exp_center=123))
+    wu = tb(lcg.bf16_normalish(23, (inter, h), exp_center=123))
+    wd = tb(lcg.bf16_normalish(24, (h, inter), exp_center=122))
+    idx = torch.from_numpy(lcg.permutation(25, h))
+    return m, h, inter, in_split, down_split, x, wg, wu, wd, idx
+
+
+def _worker_mlp(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        m, h, inter, in_split, down_split, x, wg, wu, wd, idx = _mlp_inputs()
+        mlp = tp.TPMLP(wg, wu, wd, idx, in_split, down_split, rank=rank, world=world, group=dist.group.WORLD, ops=OracleOps)
+        y = mlp(x.reshape(2, m // 2, h))
+        col = tp.ColumnParallelLinear(wg, idx, *in_split, rank=rank, world=world, group=dist.group.WORLD, ops=OracleOps,
+                                      gather_output=True)
+        g = col(x)
+        ret[rank] = (mlp.widths, y.reshape(m, h).float().numpy(), g.float().numpy(), col.features.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_megatron_mlp_and_column_parallel():
+    world = 2
+    port = 33500 + os.getpid() % 2000
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_worker_mlp, args=(world, port, ret), nprocs=world, join=True)
+        res = dict(ret)
+    m, h, inter, in_split, down_split, x, wg, wu, wd, idx = _mlp_inputs()
+    bits = OracleOps._bits
+    mm = lambda a, b, r: o.matmul(a[0], b[0], a[1], b[1], a[2], b[2], a[3], b[3], a[4], b[4], a[5], b[5], rounding=r)
+    # unsharded oracle chain: quantize -> gate, up (reference rounding) -> silu*mul + quantize -> down
+    qx = o.reorder_quantize(bits(x), idx.numpy(), *in_split, "x")
+    g = mm(qx, o.reorder_quantize(bits(wg), idx.numpy(), *in_split, "w4"), "reference")
+    u = mm(qx, o.reorder_quantize(bits(wu), idx.numpy(), *in_split, "w4"), "reference")
+    qh = o.activate_quantize(g, u, *down_split)
+    qd = o.downproj_quantize(bits(wd), *down_split, True)
+    want, f64 = o.matmul(qh[0], qd[0], qh[1], qd[1], qh[2], qd[2], qh[3], qd[3], qh[4], qd[4], qh[5], qd[5], rounding="fused",
+                         return_f64=True)
+    # column-parallel: the gathered gate output is the unsharded gate output, bit for bit (no reduction involved)
+    assert np.array_equal(res[0][2], o.bf16_to_f32(g)) and np.array_equal(res[1][2], o.bf16_to_f32(g))
+    assert np.array_equal(np.concatenate([res[0][3], res[1][3]]), np.arange(inter))
+    # the MLP: both ranks hold the same sum; the shards cover the intermediate features exactly once
+    assert np.array_equal(res[0][1], res[1][1])
+    assert [a + b for a, b in zip(res[0][0], res[1][0])] == list(down_split)
+    got = res[0][1].astype(np.float64)
+    a = [o.dequant_segment(qh[i], qh[3 + i], m, down_split[i], f) for i, f in enumerate(("fp4", "fp6", "fp8"))]
+    b = [o.dequant_segment(qd[i], qd[3 + i], h, down_split[i], "fp4") for i in range(3)]
+    S = sum(np.abs(ai).astype(np.float64) @ np.abs(bi).astype(np.float64).T for ai, bi in zip(a, b))
+    assert np.all(np.abs(got - f64) <= 2.0 ** -7 * (np.abs(f64) + 0.25 * S) + 1e-30)
+    assert np.linalg.norm(got - f64) / np.linalg.norm(f64) < 4e-3
+
+
+def test_shard_positions_partition_the_intermediate_features():
+    for split in ((512, 128, 384), (12288, 1024, 1024), (3584, 256, 256)):
+        for world in (1, 2, 4, 8):
+            plan = tp.plan_k_shards(*split, world)
+            pos = torch.cat([tp.shard_positions(*split, plan[r]) for r in range(world)])
+            assert torch.equal(torch.sort(pos).values, torch.arange(sum(split)))

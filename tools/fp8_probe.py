@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 from micromix_amd import _lib
-lib = _lib.load()
+lib = _lib.load_diag()
 dev = torch.device("cuda:0")
 
 def run(shape, ea, eb, a, b, sa, sb):

@@ -11,7 +11,8 @@ x, w, idx = [t.to(dev) for t in bench.synth_inputs()]
 M = N = K = 4096
 out = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
 clk = torch.zeros((4096, 4), dtype=torch.int64, device=dev)
-for split in ((0, 0, 4096), (4096, 0, 0), (2048, 128, 1920)):
+SPLITS = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]] or [(0, 0, 4096), (4096, 0, 0), (2048, 128, 1920)]
+for split in SPLITS:
     b = mixedgemm.reorder_quantize_w4(w, idx, *split)
     a = mixedgemm.reorder_quantize_x(x, idx, *split)
     f = lambda: mixedgemm.matmul(a[0], b[0], a[1], b[1], a[2], b[2], a[3], b[3], a[4], b[4], a[5], b[5], out=out)

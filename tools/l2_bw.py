@@ -3,7 +3,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 from micromix_amd import _lib
-lib = _lib.load(); dev = torch.device("cuda:0")
+lib = _lib.load_diag(); dev = torch.device("cuda:0")
 sink = torch.zeros(4, device=dev)
 buf = torch.randint(0, 255, (256 << 20,), dtype=torch.uint8, device=dev)
 st = lambda: torch.cuda.current_stream().cuda_stream

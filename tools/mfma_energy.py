@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 from micromix_amd import _lib
-lib = _lib.load(); dev = torch.device("cuda:0")
+lib = _lib.load_diag(); dev = torch.device("cuda:0")
 rng = np.random.default_rng(0)
 sink = torch.zeros(4, device=dev)
 seed = rng.integers(0, 256, size=(128, 32), dtype=np.uint16).astype(np.uint8)

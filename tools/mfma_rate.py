@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 from micromix_amd import _lib
-lib = _lib.load(); dev = torch.device("cuda:0")
+lib = _lib.load_diag(); dev = torch.device("cuda:0")
 rng = np.random.default_rng(0)
 ELS = ("fp4", "fp6", "fp8")
 sink = torch.zeros(4, device=dev)
