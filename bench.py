@@ -9,17 +9,26 @@ Workload (BASELINE.json configs[1]): ONE mixed-MX GEMM, M = N = K = 4096, all-MX
 (p8_num = 4096), weights pre-packed the way QLinearLayer deploys them (MXFP4, "w4" mode:
 A fp8 x B fp4 through mixedgemm.matmul).  A "step" is one `mixedgemm.matmul` call on operands
 already resident in HBM; `value` = 2*M*N*K*steps / time in TFLOP/s (the reference's own TFLOPS
-convention, mgemm/benchmark/mxf4f6f8_bench.cu:165-167).  The same line also carries
-  * `roofline`   : the GEMM kernel's per-launch duration from HIP events inside the timed region,
-                   against the dense MFMA peak for fp8 operands (MI355X_MICROARCH.md: ~5 PF);
-  * `qlinear`    : tokens/s of the full QLinearLayer.forward hot path (reorder_quantize_x + matmul),
-                   timed in a second loop of the same length, and the matching-precision "w" mode;
-  * `cpu_baseline`: the CPU oracle (a port of the same algorithm; the reference has no CPU path,
-                   see BASELINE.md) timed on a bounded row sample on this host.
-With --gpus N > 1 (one process per GPU, RCCL): the north-star tensor-parallel path -- each rank holds
-a 128-aligned K-shard of every reordered segment (weights AND activation columns), computes a partial
-[M, N] product and the partials are summed with one RCCL all-reduce on the bf16 output.  Total work is
-fixed ("scaling": "strong"); `value` is still 2*M*N*K*steps / max-over-ranks time.
+convention, mgemm/benchmark/mxf4f6f8_bench.cu:165-167).
+
+Clocks: the chip ramps its clock over the first ~second of load, and a short run (--steps 20) would be measured on
+the ramp.  So, independent of --warmup, an UNTIMED settle phase of back-to-back GEMM launches (>= SETTLE_S seconds,
+`prewarm_s` in the line) runs right before the timed region, and every kernel time quoted below is taken in that
+same regime.
+
+The line also carries
+  * `roofline`   : the GEMM kernel's per-launch duration from HIP events attached to each dispatch, against the dense
+                   MFMA peak of the operand precision (MI355X_MICROARCH.md: fp8 operands ~5.03 PF, fp6/fp4 ~10.07 PF);
+  * `mixed`      : the same for the mixed (p4, p6, p8) splits of SURVEY.md section 8d, each against its per-precision
+                   roofline time t* = sum_seg 2*M*N*K_seg / peak(seg);
+  * `qlinear`    : tokens/s of the full QLinearLayer.forward hot path (reorder_quantize_x + matmul);
+  * `cpu_baseline`: the CPU port of QLinearLayer.forward (oracle quantizer + dequantise + fp32 torch.matmul with the reference's
+                   rounding order; the reference has no CPU path) timed on this host at M in {1, 128, 2048}.
+With --gpus N > 1 (one process per GPU, RCCL): the north-star tensor-parallel path -- each rank holds a 128-aligned K-shard of
+every reordered segment (weights AND activation columns), computes a partial [M, N] product and the partials are summed with
+one RCCL all-reduce on the bf16 output.  Total work is fixed ("scaling": "strong"); `value` is 2*M*N*K*steps / max-over-ranks
+time; `tp` splits a step into `gemm_us` and `allreduce_us` (events on the compute stream) and lists the payload and the
+per-rank roofline; `tp_mlp` times the Megatron pairing (gate/up column-parallel -> down row-parallel, ONE all-reduce per MLP).
 """
 from __future__ import annotations
 
@@ -37,48 +46,73 @@ sys.path.insert(0, ROOT)
 M = N = K = 4096
 SPLIT = (0, 0, 4096)          # (p4_num, p6_num, p8_num): all-MXFP8 activations
 PEAK_TFLOPS_FP8 = 5033.0      # 2048 flop/clk/SIMD * 4 SIMD * 256 CU * 2.4 GHz (MI355X_MICROARCH.md, dense)
-PEAK_TFLOPS_FP4 = 10066.0
+PEAK_TFLOPS_FP4 = 10066.0     # fp6 / fp4 operands: 4096 flop/clk/SIMD
+SETTLE_S = 1.5
+# mixed splits of SURVEY.md section 8d (name, M, N, K, split)
+MIXED = [("q_o_2048_128_1920", 4096, 4096, 4096, (2048, 128, 1920)), ("q_o_3072_896_128", 4096, 4096, 4096, (3072, 896, 128)),
+         ("q_o_all_fp4", 4096, 4096, 4096, (4096, 0, 0)), ("down_12288_1024_1024", 4096, 4096, 14336, (12288, 1024, 1024))]
 
 
-def synth_inputs(seed=0):
+def roofline_time_s(m, n, split):
+    """t* = sum over segments of 2*M*N*K_seg / peak(segment operand precision): activations fp4 | fp6 | fp8 against fp4
+    weights run at the fp4 / fp4 / fp8 MFMA rate."""
+    kn, ks, ko = split
+    return 2.0 * m * n * (kn + ks) / (PEAK_TFLOPS_FP4 * 1e12) + 2.0 * m * n * ko / (PEAK_TFLOPS_FP8 * 1e12)
+
+
+def synth_inputs(seed=0, m=M, n=N, k=K):
     """X ~ N(0,1) bf16 with 1 % outlier channels x20; W ~ N(0, 0.02); reorder index = argsort of the
     per-channel mean |x| (reorder_indices.py:64-69).  torch CPU generator, seed fixed."""
     import torch
     g = torch.Generator().manual_seed(seed)
-    x = torch.randn((M, K), generator=g)
-    cols = torch.randperm(K, generator=g)[: K // 100]
+    x = torch.randn((m, k), generator=g)
+    cols = torch.randperm(k, generator=g)[: k // 100]
     x[:, cols] *= 20.0
-    w = torch.randn((N, K), generator=g) * 0.02
+    w = torch.randn((n, k), generator=g) * 0.02
     idx = torch.argsort(x.abs().mean(0)).to(torch.int16)
     return x.to(torch.bfloat16), w.to(torch.bfloat16), idx
 
 
-def cpu_baseline(x, w, idx, rows=2048, budget_s=12.0):
-    """The oracle (a CPU port of QLinearLayer.forward: quantize-x + dequantise + matmul with the reference
-    rounding order) on a bounded sample of the same workload: `rows`-token forwards repeated until ~budget_s
-    seconds of CPU work have been timed.  Weights are packed outside the timed region, exactly as on the GPU."""
+def cpu_baseline(x, w, idx, budget_s=18.0):
+    """the CPU port of QLinearLayer.forward for N = K = 4096 at M in {1, 128, 2048} -- oracle
+    quantize-x (numpy) + dequantise + fp32 torch.matmul on all host cores + bf16 rounding after each segment (the reference's
+    rounding order); the weight is packed AND dequantised once outside the timed region (a CPU fake-quant layer would hold
+    it that way).  Median of >= 3 repeats after one warm-up, bounded to ~budget_s of CPU time in all."""
     import torch
     from oracle import mx_oracle as o
-    try:
-        from threadpoolctl import threadpool_info
-        cores = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
-    except Exception:
-        cores = os.cpu_count() or 1
+    cores = torch.get_num_threads()
     bits = lambda t: t.contiguous().view(torch.int16).numpy().view(np.uint16)
-    xb, wb, ib = bits(x[:rows]), bits(w), idx.numpy()
-    packed = o.qlinear_pack_weight(wb, ib, *SPLIT, "w4")
-    o.qlinear_forward(xb[:8], ib, *SPLIT, packed)               # warm-up
-    reps, dt = 0, 0.0
-    t0 = time.perf_counter()
-    while dt < budget_s and reps < 64:
-        o.qlinear_forward(xb, ib, *SPLIT, packed)
-        reps += 1
-        dt = time.perf_counter() - t0
-    tokens = rows * reps
-    return {"value": round(2.0 * tokens * N * K / dt / 1e12, 4), "unit": "TFLOP/s", "cores": int(cores), "kind": "port",
-            "tokens_per_s": round(tokens / dt, 1),
-            "sample": f"{reps} x {rows} of {M} token rows, full N=K=4096: oracle quantize-x + dequant + fp64 matmul + bf16 "
-                      f"rounding per segment, {dt:.1f} s of CPU time"}
+    ib = idx.numpy()
+    packed = o.qlinear_pack_weight(bits(w), ib, *SPLIT, "w4")
+    wdeq = [torch.from_numpy(d.astype(np.float32)) if d is not None else None for d in o.dequant_operand(packed, "w", "w4")]
+    fmts = ("fp4", "fp6", "fp8")
+
+    def forward(xb):
+        q = o.reorder_quantize(xb, ib, *SPLIT, "x")
+        d = torch.zeros((xb.shape[0], N), dtype=torch.float32)
+        for i, kseg in enumerate(SPLIT):
+            if kseg:
+                a = torch.from_numpy(o.dequant_segment(q[i], q[3 + i], xb.shape[0], kseg, fmts[i], np.float32))
+                d = (torch.matmul(a, wdeq[i].t()) + d).to(torch.bfloat16).to(torch.float32)   # D = bf16(acc + D), gemm.cu:75-77
+        return d
+
+    by_rows, spent = {}, 0.0
+    for rows in (1, 128, 2048):
+        xb = bits(x[:rows])
+        forward(xb)
+        ts = []
+        while len(ts) < 3 or (len(ts) < 9 and spent < budget_s * (0.2 if rows < 2048 else 1.0)):
+            t0 = time.perf_counter()
+            forward(xb)
+            ts.append(time.perf_counter() - t0)
+            spent += ts[-1]
+        t = float(np.median(ts))
+        by_rows[str(rows)] = {"ms": round(t * 1e3, 3), "tokens_per_s": round(rows / t, 1), "tflops": round(2.0 * rows * N * K / t / 1e12, 4)}
+    return {"value": by_rows["2048"]["tflops"], "unit": "TFLOP/s", "cores": int(cores), "kind": "port",
+            "tokens_per_s": by_rows["2048"]["tokens_per_s"], "by_rows": by_rows,
+            "sample": f"QLinearLayer.forward port at M in (1, 128, 2048) of the {M} token rows, full N=K=4096: oracle quantize-x + "
+                      f"dequantise + fp32 torch.matmul + bf16 rounding per segment, median of >=3 repeats, {spent:.1f} s of CPU time; "
+                      "`value` is the M=2048 figure"}
 
 
 def load_traffic():
@@ -97,6 +131,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="headline GEMM only (profiling runs)")
     args = ap.parse_args()
 
     import torch
@@ -104,7 +139,7 @@ def main():
     from micromix_amd import _lib, mixedgemm
     from micromix_amd import tp as tpmod
 
-    _lib.load()  # fail loudly if the HIP library is missing
+    lib = _lib.load()  # fail loudly if the HIP library is missing
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -133,6 +168,34 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def mm(a, b, out):
+        return mixedgemm.matmul(a[0], b[0], a[1], b[1], a[2], b[2], a[3], b[3], a[4], b[4], a[5], b[5], out=out)
+
+    def settle(fn, seconds=SETTLE_S):
+        """untimed: back-to-back launches for at least `seconds` so that the clock the timed region sees is the sustained one"""
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            for _ in range(100):
+                fn()
+            torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    def kernel_us(fn, steps):
+        """mean duration of the tiled-GEMM dispatch inside fn(): HIP events attached to the dispatch itself (hipExtLaunchKernel
+        start/stop events, mm_diag_set_kernel_events) on the stream the kernel runs on -- they bracket exactly what rocprofv3's
+        kernel trace reports.  (Events recorded AROUND the call would include the ~4 us launch gap in every sample.)"""
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        for e0, e1 in evs:      # torch creates the hipEvent_t on first record
+            e0.record()
+            e1.record()
+        torch.cuda.synchronize()
+        for e0, e1 in evs:
+            lib.mm_diag_set_kernel_events(e0.cuda_event, e1.cuda_event)
+            fn()
+        lib.mm_diag_set_kernel_events(None, None)
+        torch.cuda.synchronize()
+        return float(np.mean([e0.elapsed_time(e1) for e0, e1 in evs])) * 1e3
+
     extra = {}
     if world == 1:
         b = mixedgemm.reorder_quantize_w4(w, idx, *SPLIT)
@@ -140,7 +203,7 @@ def main():
         out = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
 
         def step():
-            mixedgemm.matmul(a[0], b[0], a[1], b[1], a[2], b[2], a[3], b[3], a[4], b[4], a[5], b[5], out=out)
+            mm(a, b, out)
         parallelism = "single GPU"
     else:
         layer = tpmod.TPShardedLinear(w, idx, *SPLIT, rank=rank, world=world, group=dist.group.WORLD)
@@ -150,7 +213,6 @@ def main():
         def step():
             layer.matmul_allreduce(a, out=out)
         parallelism = f"tp{world}: K-shard (row-parallel) + RCCL all-reduce(bf16 [M,N])"
-        extra["tp_shard_columns"] = layer.shard_widths
 
     for _ in range(args.warmup):
         step()
@@ -175,6 +237,7 @@ def main():
             print(f"[bench] hipGraph capture failed ({e}); timing stream launches", file=sys.stderr)
             graph = None
     extra_launch = "one hipGraph of K GEMM launches" if graph is not None else "K stream launches"
+    prewarm_s = settle(step)
     # timed region: exactly K steps, nothing else
     barrier()
     t0 = time.perf_counter()
@@ -185,34 +248,19 @@ def main():
             step()
     barrier()
     dt = time.perf_counter() - t0
-    # Kernel duration for the roofline: a second pass of the same K steps with HIP events attached to the GEMM dispatch
-    # itself (hipExtLaunchKernel start/stop events, mm_diag_set_kernel_events) on the stream the kernel runs on; they
-    # bracket exactly what rocprofv3's kernel trace reports.  It is a separate pass because attaching events widens the gap
-    # between consecutive launches by ~4 us (it would cost `value` 5-7 %), and events recorded AROUND the call would
-    # include that gap in every sample.
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    if world == 1:
-        from micromix_amd import _lib
-        lib = _lib.load()
-        for e0, e1 in evs:      # torch creates the hipEvent_t on first record
-            e0.record()
-            e1.record()
+    # the same K steps as plain stream launches (reported next to the graph figure; not `value`)
+    stream_ms = None
+    if graph is not None:
         torch.cuda.synchronize()
-        for e0, e1 in evs:
-            lib.mm_diag_set_kernel_events(e0.cuda_event, e1.cuda_event)
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
             step()
-        lib.mm_diag_set_kernel_events(None, None)
-    else:
-        for e0, e1 in evs:      # per-step device time of GEMM + all-reduce on this rank's stream
-            e0.record()
-            step()
-            e1.record()
-    barrier()
+        torch.cuda.synchronize()
+        stream_ms = (time.perf_counter() - t1) * 1e3 / args.steps
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    kern_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in evs]))
     ms_per_step = dt * 1e3 / args.steps
     flop = 2.0 * M * N * K
     value = flop / (ms_per_step * 1e-3) / 1e12
@@ -220,29 +268,58 @@ def main():
     result = {
         "metric": "mixed-MX GEMM TFLOPS (Llama-3-8B 4096x4096x4096, all-MXFP8 activations, MXFP4 weights)",
         "value": round(value, 2), "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "prewarm_s": round(prewarm_s, 2),
         "ms_per_step": round(ms_per_step, 5), "higher_is_better": True,
-        "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": "mxfp8 x mxfp4 -> f32 acc -> bf16",
+        "scaling": "strong", "vs_baseline": None, "dtype": "mxfp8 x mxfp4 -> f32 acc -> bf16",
         "data": "synthetic",
         "config": {"workload": "BASELINE.json configs[1]: single 4096x4096x4096 mixed-MX GEMM, (p4,p6,p8)=(0,0,4096), "
                                "w4 weights (production QLinearLayer mode)",
                    "M": M, "N": N, "K": K, "split": list(SPLIT), "weight_mode": "w4", "parallelism": parallelism,
                    "launch": extra_launch},
     }
+    if stream_ms is not None:
+        result["stream_launch_ms_per_step"] = round(stream_ms, 5)
 
     if rank == 0 and world == 1:
         traffic = load_traffic()
-        achieved = flop / (kern_ms * 1e-3) / 1e12
+        kus = kernel_us(step, args.steps)
+        achieved = flop / (kus * 1e-6) / 1e12
+        wmode = 1   # MM_W_FP4
         result["roofline"] = {
             "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_TFLOPS_FP8, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_TFLOPS_FP8, 4),
             "traffic": traffic.get("hbm_bytes_per_launch") if traffic else None,
-            "kernel": "mm::g256::mx_gemm256_kernel<true,false> (fused three-segment scaled-MFMA GEMM, 256x256 tiles)",
-            "kernel_us": round(kern_ms * 1e3, 2), "kernel_us_source": "HIP events attached to each GEMM dispatch, second pass of K steps",
+            "traffic_source": (f"profiles/gemm_traffic.json ({traffic.get('collected', 'rocprofv3 --pmc passes')}); "
+                               "NOT measured in this run") if traffic else None,
+            "kernel": lib.mm_matmul_describe(M, N, *SPLIT, wmode, 0, 0).decode(),
+            "kernel_us": round(kus, 2), "kernel_us_source": "HIP events attached to each GEMM dispatch, K stream launches after the settle phase",
             "algorithmic_flop_per_launch": flop,
             "algorithmic_bytes_per_launch": M * K + N * K // 2 + (M + N) * K // 32 + 2 * M * N,
             "note": "peak = dense fp8-operand scaled-MFMA rate; A is fp8 so the fp8 rate applies to the whole launch",
         }
-        # second loop of the same length: the full QLinearLayer.forward hot path, and the "w" weight mode
+    if rank == 0 and world == 1 and not args.no_extras:
+        # ---- mixed splits against their per-precision rooflines (t* = sum_seg 2*M*N*K_seg / peak(seg)) ----
+        mixed = {}
+        for name, mm_, nn_, kk_, split in MIXED:
+            if (mm_, nn_, kk_) == (M, N, K):
+                xs, ws, ids = x, w, idx
+            else:
+                xc, wc, ic = synth_inputs(1, mm_, nn_, kk_)
+                xs, ws, ids = xc.to(dev), wc.to(dev), ic.to(dev)
+            am = mixedgemm.reorder_quantize_x(xs, ids, *split)
+            bm = mixedgemm.reorder_quantize_w4(ws, ids, *split)
+            om = out if (mm_, nn_) == (M, N) else torch.empty((mm_, nn_), dtype=torch.bfloat16, device=dev)
+            f = lambda: mm(am, bm, om)
+            settle(f, 0.4)
+            us = kernel_us(f, args.steps)
+            tstar = roofline_time_s(mm_, nn_, split) * 1e6
+            mixed[name] = {"M": mm_, "N": nn_, "K": kk_, "split": list(split), "kernel_us": round(us, 2),
+                           "tflops": round(2.0 * mm_ * nn_ * kk_ / us / 1e6, 1), "roofline_us": round(tstar, 2),
+                           "frac": round(tstar / us, 4), "kernel": lib.mm_matmul_describe(mm_, nn_, *split, 1, 0, 0).decode()}
+            del am, bm
+        result["mixed"] = mixed
+
+        # ---- the full QLinearLayer.forward hot path, and the "w" weight mode ----
         def timed(fn):
             for _ in range(args.warmup):
                 fn()
@@ -255,7 +332,8 @@ def main():
 
         def fwd():
             q = mixedgemm.reorder_quantize_x(x, idx, *SPLIT)
-            mixedgemm.matmul(q[0], b[0], q[1], b[1], q[2], b[2], q[3], b[3], q[4], b[4], q[5], b[5], out=out)
+            mm(q, b, out)
+        settle(fwd, 0.4)
         t_fwd = timed(fwd)
         fwd_launch = "stream launches"
         if graph is not None:       # the same K forwards as one hipGraph (as the GEMM steps above)
@@ -277,44 +355,91 @@ def main():
                 print(f"[bench] hipGraph capture of the forward failed ({e})", file=sys.stderr)
         # quantizer kernel alone: direct C-ABI calls on preallocated outputs (the op-level call spends ~20 us of host
         # time on six allocations, which would hide the 11 us kernel)
-        lib = _lib.load()
         qo = mixedgemm.reorder_quantize_x(x, idx, *SPLIT)
         pp = lambda t: t.data_ptr() if t.numel() else None
         stream = torch.cuda.current_stream().cuda_stream
         t_q = timed(lambda: lib.mm_reorder_quantize(x.data_ptr(), M, K, idx.data_ptr(), *SPLIT, 0, pp(qo[0]), pp(qo[1]), pp(qo[2]),
                                                     pp(qo[3]), pp(qo[4]), pp(qo[5]), stream))
         bw = mixedgemm.reorder_quantize_w(w, idx, *SPLIT)
-        t_w = timed(lambda: mixedgemm.matmul(a[0], bw[0], a[1], bw[1], a[2], bw[2], a[3], bw[3], a[4], bw[4], a[5], bw[5], out=out))
-        mixed = (2048, 128, 1920)   # the reference's own bench constants (bench_reorder_gemm.cu:28-30)
-        am = mixedgemm.reorder_quantize_x(x, idx, *mixed)
-        bm = mixedgemm.reorder_quantize_w4(w, idx, *mixed)
-        t_m = timed(lambda: mixedgemm.matmul(am[0], bm[0], am[1], bm[1], am[2], bm[2], am[3], bm[3], am[4], bm[4], am[5], bm[5], out=out))
+        fw = lambda: mm(a, bw, out)
+        us_w = kernel_us(fw, args.steps)
         q_bytes = 2 * M * K + M * K + M * K // 32 + 2 * K
         result["qlinear"] = {
             "tokens_per_s": round(M / t_fwd, 1), "forward_us": round(t_fwd * 1e6, 2), "forward_launch": fwd_launch,
             "quantize_x_kernel_us": round(t_q * 1e6, 2), "quantize_x_GBps": round(q_bytes / t_q / 1e9, 1),
             "quantize_x_frac_of_8TBps": round(q_bytes / t_q / 8e12, 4),
-            "gemm_w_mode_tflops": round(flop / t_w / 1e12, 2),
-            "gemm_mixed_2048_128_1920_w4_tflops": round(flop / t_m / 1e12, 2),
+            "gemm_w_mode_kernel_us": round(us_w, 2), "gemm_w_mode_tflops": round(flop / us_w / 1e6, 2),
         }
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(x_cpu, w_cpu, idx_cpu)
     if world > 1:
-        # the same GEMM with rows instead of K split across the GPUs (every rank multiplies its own 4096 token rows by the
-        # replicated weights, no exchange): what the node delivers when the linear layer is used data-parallel
-        b = mixedgemm.reorder_quantize_w4(w, idx, *SPLIT)
-        a = mixedgemm.reorder_quantize_x(x, idx, *SPLIT)
-        for _ in range(args.warmup):
-            mixedgemm.matmul(a[0], b[0], a[1], b[1], a[2], b[2], a[3], b[3], a[4], b[4], a[5], b[5], out=out)
+        # ---- GEMM and all-reduce separately (events on the compute stream; the all-reduce is waited for on that stream) ----
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+        for e0, e1, e2 in ev:
+            e0.record()
+            if not layer.empty:
+                layer.ops.matmul(a, layer.packed_w, out=out)
+            else:
+                out.zero_()
+            e1.record()
+            dist.all_reduce(out, op=dist.ReduceOp.SUM)
+            e2.record()
         barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            mixedgemm.matmul(a[0], b[0], a[1], b[1], a[2], b[2], a[3], b[3], a[4], b[4], a[5], b[5], out=out)
-        barrier()
-        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        extra["row_parallel_no_exchange"] = {"value": round(world * flop / (float(t.item()) / args.steps) / 1e12, 2), "unit": "TFLOP/s",
-                                             "scaling": "weak", "global_rows": world * M}
+        gemm_us = float(np.mean([e[0].elapsed_time(e[1]) for e in ev])) * 1e3
+        ar_us = float(np.mean([e[1].elapsed_time(e[2]) for e in ev])) * 1e3
+        widths = layer.shard_widths
+        shard_flop = 2.0 * M * N * sum(widths)
+        tstar = roofline_time_s(M, N, widths) * 1e6
+        stats = torch.tensor([gemm_us, ar_us], dtype=torch.float64, device=dev)
+        dist.all_reduce(stats, op=dist.ReduceOp.MAX)
+        extra["tp"] = {
+            "layout": "K-shard (row-parallel), one all-reduce per linear", "shard_columns_rank0": widths,
+            "gemm_us_max_over_ranks": round(float(stats[0]), 2), "allreduce_us_max_over_ranks": round(float(stats[1]), 2),
+            "allreduce_payload_bytes": M * N * 2,
+            "rank0_roofline": {"bound": "mfma", "kernel_us": round(gemm_us, 2), "roofline_us": round(tstar, 2),
+                               "frac": round(tstar / gemm_us, 4) if gemm_us > 0 else None,
+                               "achieved": round(shard_flop / gemm_us / 1e6, 1) if gemm_us > 0 else None, "unit": "TFLOP/s"},
+            "note": "events on the compute stream: gemm = the shard's fused GEMM, allreduce = RCCL sum of the bf16 [M,N] partials",
+        }
+        if not args.no_extras:
+            # the same GEMM with rows instead of K split across the GPUs (every rank multiplies its own 4096 token rows by the
+            # replicated weights, no exchange): what the node delivers when the linear layer is used data-parallel
+            b = mixedgemm.reorder_quantize_w4(w, idx, *SPLIT)
+            a2 = mixedgemm.reorder_quantize_x(x, idx, *SPLIT)
+            for _ in range(args.warmup):
+                mm(a2, b, out)
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                mm(a2, b, out)
+            barrier()
+            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            extra["row_parallel_no_exchange"] = {"value": round(world * flop / (float(t.item()) / args.steps) / 1e12, 2), "unit": "TFLOP/s",
+                                                 "scaling": "weak", "global_rows": world * M}
+            del b, a2
+            # ---- Megatron pairing: Llama-3-8B MLP (hidden 4096, intermediate 14336), ONE all-reduce per MLP ----
+            hid, inter = 4096, 14336
+            g = torch.Generator(device=dev).manual_seed(7)
+            rnd = lambda *s: (torch.randn(s, generator=g, device=dev) * 0.02).to(torch.bfloat16)
+            mlp = tpmod.TPMLP(rnd(inter, hid), rnd(inter, hid), rnd(hid, inter), idx, (2048, 128, 1920), (12288, 1024, 1024),
+                              rank=rank, world=world, group=dist.group.WORLD)
+            for _ in range(max(3, args.warmup // 10)):
+                mlp(x)
+            barrier()
+            n_mlp = max(5, args.steps // 10)
+            t0 = time.perf_counter()
+            for _ in range(n_mlp):
+                mlp(x)
+            barrier()
+            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            mlp_s = float(t.item()) / n_mlp
+            extra["tp_mlp"] = {
+                "layout": "gate/up column-parallel -> activate_quantize_x on the local slice -> down row-parallel -> one all-reduce",
+                "tokens": M, "hidden": hid, "intermediate": inter, "mlp_us": round(mlp_s * 1e6, 1),
+                "tflops": round(2.0 * M * hid * inter * 3 / mlp_s / 1e12, 1), "allreduce_payload_bytes": M * hid * 2,
+                "allreduce_payload_bytes_if_every_linear_were_k_sharded": 2 * M * inter * 2 + M * hid * 2}
     if rank == 0:
         result.update(extra)
         print(json.dumps(result), flush=True)

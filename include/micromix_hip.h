@@ -196,6 +196,11 @@ int mm_qlinear_decode(const void *X_bf16, const int16_t *reorder_index, const ui
                       const uint8_t *SFBN, const uint8_t *SFBS, const uint8_t *SFBO, int M, int N, int KN, int KS, int KO,
                       int wmode, int flags, const void *bias_bf16, void *D_bf16, mm_stream_t stream);
 
+/* Which kernel(s) and how many workgroups mm_matmul / mm_matmul_ws launch for this problem on the CURRENT device (the same
+ * decision code as the launcher; workspace_bytes = 0 means "no workspace", i.e. never split-K).  Returns a string in a
+ * thread-local buffer, valid until the calling thread's next call.  Used by bench.py to name the kernel it timed. */
+const char *mm_matmul_describe(int M, int N, int KN, int KS, int KO, int wmode, int flags, size_t workspace_bytes);
+
 /* bindings.cpp:700 `m.def("test_function", ...)`: the reference module's liveness probe; returns the same constant string. */
 const char *mm_test_function(void);
 

@@ -138,6 +138,13 @@ size_t mm_matmul_workspace_bytes(int M, int N, int KN, int KS, int KO, int wmode
     return mm::mx_gemm_workspace_bytes(M, N, K, (flags & MM_SPLIT_K_ALWAYS) != 0);
 }
 
+const char *mm_matmul_describe(int M, int N, int KN, int KS, int KO, int wmode, int flags, size_t workspace_bytes) {
+    if (M <= 0 || N <= 0 || KN < 0 || KS < 0 || KO < 0 || (KN % 128) || (KS % 128) || (KO % 128) || KN + KS + KO == 0) return "none";
+    if (M <= 64) return "mm::skinny::mx_gemm_skinny*_kernel (weight streaming, M <= 64)";
+    const int K[3] = {KN, KS, KO};
+    return mm::describe_mx_gemm256(M, N, K, wmode == MM_W_FP4, workspace_bytes, (flags & MM_SPLIT_K_ALWAYS) != 0);
+}
+
 int mm_matmul(const uint8_t *AN, const uint8_t *BN, const uint8_t *AS, const uint8_t *BS, const uint8_t *AO,
               const uint8_t *BO, const uint8_t *SFAN, const uint8_t *SFBN, const uint8_t *SFAS, const uint8_t *SFBS,
               const uint8_t *SFAO, const uint8_t *SFBO, int M, int N, int KN, int KS, int KO, int wmode, int flags,

@@ -24,6 +24,7 @@
 //    each wave's tile through LDS (free at that point) and stores whole 256-byte rows.
 #include <hip/hip_ext.h>
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <type_traits>
 #include <utility>
@@ -212,62 +213,109 @@ static hipError_t launch_tile(KernelT kern, DynamicLdsOnce &attr, int lds_bytes,
     return hipGetLastError();
 }
 
-hipError_t launch_mx_gemm256(const GemmArgs &a, bool w4, hipStream_t stream) {
-    static DynamicLdsOnce done[6];
-    const int tn = (a.N + 255) / 256;
-    const int tiles256 = ((a.M + 255) / 256) * tn, tiles128 = ((a.M + 127) / 128) * tn;
-    if (a.ws != nullptr) {
-        GemmArgs b = a;
-        b.splits = plan_splits(a.M, a.N, a.K, a.force_split != 0, b.split_first);
-        if (b.splits && (size_t)tiles128 * b.splits * SPLIT_WG_FLOATS * sizeof(float) <= a.ws_bytes) {
-            hipError_t e = w4 ? launch_tile(g128::mx_gemm256_kernel<true, true>, done[4], g128::Lds<true>::TOTAL, tiles128 * b.splits, g128::NT, b, stream)
-                              : launch_tile(g128::mx_gemm256_kernel<false, true>, done[5], g128::Lds<false>::TOTAL, tiles128 * b.splits, g128::NT, b, stream);
-            if (e != hipSuccess) return e;
-            const int total = tiles128 * SPLIT_WG_FLOATS;
-            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((total / 4 + 255) / 256), dim3(256), 0, stream, b, tn, total);
-            return hipGetLastError();
+// Which kernel(s) a problem runs on: decided once here, used by the launcher and by mm_matmul_describe.
+enum TileKind { TK_SPLITK, TK_G64, TK_G256_TAIL, TK_G256, TK_G128 };
+struct TilePlan {
+    TileKind kind;
+    int tn, tiles256, tiles128, tiles64, tm256, tm128, tail_cols;
+    int splits, split_first[4];
+};
+
+static TilePlan plan_tiles(int M, int N, const int K[3], bool have_ws, size_t ws_bytes, bool force_split) {
+    TilePlan p{};
+    p.tn = (N + 255) / 256;
+    p.tm256 = (M + 255) / 256;
+    p.tm128 = (M + 127) / 128;
+    p.tiles256 = p.tm256 * p.tn;
+    p.tiles128 = p.tm128 * p.tn;
+    p.tiles64 = p.tm128 * ((N + 127) / 128);
+    if (have_ws) {
+        p.splits = plan_splits(M, N, K, force_split, p.split_first);
+        if (p.splits && (size_t)p.tiles128 * p.splits * SPLIT_WG_FLOATS * sizeof(float) <= ws_bytes) {
+            p.kind = TK_SPLITK;
+            return p;
         }
+        p.splits = 0;
     }
-    static const int force = env_int("MICROMIX_GEMM_TILE", 0);   // kernel-developer override: 256 or 128
+    static const int force = env_int("MICROMIX_GEMM_TILE", 0);   // kernel-developer override: 256, 128 or 64
     static const int tail_split = env_int("MICROMIX_GEMM_TAIL", 1);
     const int cus = device_cus();
     // One workgroup fits per CU, so a launch runs in rounds of `cus` tiles.  256-row tiles move the fewest L2->LDS bytes per
     // flop; a round of 128-row tiles takes ~0.62 of a round of 256-row tiles (measured).  So 128-row tiles pay exactly when
     // they still fit in ONE round (tiles128 <= cus, i.e. at most half of the CUs would get a 256-row tile): M=2048, N=4096
     // 46.5 -> 33 us; with 160 256-row tiles (320 128-row tiles = two rounds) the 256-row tiles win, 62 vs 76 us.
-    const bool use128 = force == 128 || (force != 256 && force != 64 && tiles128 <= cus);
+    const bool use128 = force == 128 || (force != 256 && force != 64 && p.tiles128 <= cus);
     // ... and when even the 128-row tiles would occupy at most half of the CUs, 128 x 128 tiles double the workgroups once
     // more (1.5x the L2->LDS bytes per flop, which does not matter while half of the chip idles): M = 1024, N = 4096.
-    const int tiles64 = ((a.M + 127) / 128) * ((a.N + 127) / 128);
-    if (force == 64 || (force == 0 && 2 * tiles128 <= cus && tiles64 <= cus)) {
-        static DynamicLdsOnce done64[2];
-        if (w4) return launch_tile(g64::mx_gemm256_kernel<true, false>, done64[0], g64::Lds<true>::TOTAL, tiles64, g64::NT, a, stream);
-        return launch_tile(g64::mx_gemm256_kernel<false, false>, done64[1], g64::Lds<false>::TOTAL, tiles64, g64::NT, a, stream);
+    if (force == 64 || (force == 0 && 2 * p.tiles128 <= cus && p.tiles64 <= cus)) {
+        p.kind = TK_G64;
+        return p;
     }
     // Tail balancing: tiles256 = q * CUs + R runs q + 1 rounds and the last one leaves CUs idle.
     // When R <= CUs / 2 and R is a whole number of tile columns, those columns are run as 128-row tiles instead (2R
     // workgroups of half the work: the last round takes half the time).  gate/up at M = 4096: 896 tiles = 3.5 rounds.
-    const int tm256 = (a.M + 255) / 256, rem = tiles256 % cus;
-    if (!use128 && tail_split && force == 0 && tiles256 > cus && rem > 0 && 2 * rem <= cus && rem % tm256 == 0) {
-        const int c = rem / tm256;
-        GemmArgs lo = a, hi = a;
-        lo.n_tile0 = 0;
-        lo.n_tiles = tn - c;
-        hi.n_tile0 = tn - c;
-        hi.n_tiles = c;
-        hipError_t e = w4 ? launch_tile(g256::mx_gemm256_kernel<true, false>, done[0], g256::Lds<true>::TOTAL, tm256 * (tn - c), g256::NT, lo, stream)
-                          : launch_tile(g256::mx_gemm256_kernel<false, false>, done[1], g256::Lds<false>::TOTAL, tm256 * (tn - c), g256::NT, lo, stream);
-        if (e != hipSuccess) return e;
-        const int tm128 = (a.M + 127) / 128;
-        return w4 ? launch_tile(g128::mx_gemm256_kernel<true, false>, done[2], g128::Lds<true>::TOTAL, tm128 * c, g128::NT, hi, stream)
-                  : launch_tile(g128::mx_gemm256_kernel<false, false>, done[3], g128::Lds<false>::TOTAL, tm128 * c, g128::NT, hi, stream);
+    const int rem = p.tiles256 % cus;
+    if (!use128 && tail_split && force == 0 && p.tiles256 > cus && rem > 0 && 2 * rem <= cus && rem % p.tm256 == 0) {
+        p.kind = TK_G256_TAIL;
+        p.tail_cols = rem / p.tm256;
+        return p;
     }
-    if (!use128) {
-        if (w4) return launch_tile(g256::mx_gemm256_kernel<true, false>, done[0], g256::Lds<true>::TOTAL, tiles256, g256::NT, a, stream);
-        return launch_tile(g256::mx_gemm256_kernel<false, false>, done[1], g256::Lds<false>::TOTAL, tiles256, g256::NT, a, stream);
+    p.kind = use128 ? TK_G128 : TK_G256;
+    return p;
+}
+
+const char *describe_mx_gemm256(int M, int N, const int K[3], bool w4, size_t ws_bytes, bool force_split) {
+    static thread_local char buf[192];
+    const TilePlan p = plan_tiles(M, N, K, ws_bytes > 0, ws_bytes, force_split);
+    const char *w = w4 ? "true" : "false";
+    switch (p.kind) {
+        case TK_SPLITK: snprintf(buf, sizeof(buf), "mm::g128::mx_gemm256_kernel<%s,true> x %d workgroups (128x256 tiles, split-K %d) + mm::splitk_reduce_kernel", w, p.tiles128 * p.splits, p.splits); break;
+        case TK_G64: snprintf(buf, sizeof(buf), "mm::g64::mx_gemm256_kernel<%s,false> x %d workgroups (128x128 tiles)", w, p.tiles64); break;
+        case TK_G256_TAIL: snprintf(buf, sizeof(buf), "mm::g256::mx_gemm256_kernel<%s,false> x %d workgroups (256x256 tiles) + mm::g128::mx_gemm256_kernel<%s,false> x %d (last %d tile columns as 128x256 tiles)", w, p.tm256 * (p.tn - p.tail_cols), w, p.tm128 * p.tail_cols, p.tail_cols); break;
+        case TK_G256: snprintf(buf, sizeof(buf), "mm::g256::mx_gemm256_kernel<%s,false> x %d workgroups (256x256 tiles)", w, p.tiles256); break;
+        default: snprintf(buf, sizeof(buf), "mm::g128::mx_gemm256_kernel<%s,false> x %d workgroups (128x256 tiles)", w, p.tiles128); break;
     }
-    if (w4) return launch_tile(g128::mx_gemm256_kernel<true, false>, done[2], g128::Lds<true>::TOTAL, tiles128, g128::NT, a, stream);
-    return launch_tile(g128::mx_gemm256_kernel<false, false>, done[3], g128::Lds<false>::TOTAL, tiles128, g128::NT, a, stream);
+    return buf;
+}
+
+hipError_t launch_mx_gemm256(const GemmArgs &a, bool w4, hipStream_t stream) {
+    static DynamicLdsOnce done[8];
+    const TilePlan p = plan_tiles(a.M, a.N, a.K, a.ws != nullptr, a.ws_bytes, a.force_split != 0);
+    switch (p.kind) {
+        case TK_SPLITK: {
+            GemmArgs b = a;
+            b.splits = p.splits;
+            for (int i = 0; i < 4; ++i) b.split_first[i] = p.split_first[i];
+            hipError_t e = w4 ? launch_tile(g128::mx_gemm256_kernel<true, true>, done[4], g128::Lds<true>::TOTAL, p.tiles128 * p.splits, g128::NT, b, stream)
+                              : launch_tile(g128::mx_gemm256_kernel<false, true>, done[5], g128::Lds<false>::TOTAL, p.tiles128 * p.splits, g128::NT, b, stream);
+            if (e != hipSuccess) return e;
+            const int total = p.tiles128 * SPLIT_WG_FLOATS;
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((total / 4 + 255) / 256), dim3(256), 0, stream, b, p.tn, total);
+            return hipGetLastError();
+        }
+        case TK_G64:
+            if (w4) return launch_tile(g64::mx_gemm256_kernel<true, false>, done[6], g64::Lds<true>::TOTAL, p.tiles64, g64::NT, a, stream);
+            return launch_tile(g64::mx_gemm256_kernel<false, false>, done[7], g64::Lds<false>::TOTAL, p.tiles64, g64::NT, a, stream);
+        case TK_G256_TAIL: {
+            const int c = p.tail_cols;
+            GemmArgs lo = a, hi = a;
+            lo.n_tile0 = 0;
+            lo.n_tiles = p.tn - c;
+            hi.n_tile0 = p.tn - c;
+            hi.n_tiles = c;
+            hipError_t e = w4 ? launch_tile(g256::mx_gemm256_kernel<true, false>, done[0], g256::Lds<true>::TOTAL, p.tm256 * (p.tn - c), g256::NT, lo, stream)
+                              : launch_tile(g256::mx_gemm256_kernel<false, false>, done[1], g256::Lds<false>::TOTAL, p.tm256 * (p.tn - c), g256::NT, lo, stream);
+            if (e != hipSuccess) return e;
+            return w4 ? launch_tile(g128::mx_gemm256_kernel<true, false>, done[2], g128::Lds<true>::TOTAL, p.tm128 * c, g128::NT, hi, stream)
+                      : launch_tile(g128::mx_gemm256_kernel<false, false>, done[3], g128::Lds<false>::TOTAL, p.tm128 * c, g128::NT, hi, stream);
+        }
+        case TK_G256:
+            if (w4) return launch_tile(g256::mx_gemm256_kernel<true, false>, done[0], g256::Lds<true>::TOTAL, p.tiles256, g256::NT, a, stream);
+            return launch_tile(g256::mx_gemm256_kernel<false, false>, done[1], g256::Lds<false>::TOTAL, p.tiles256, g256::NT, a, stream);
+        default:
+            if (w4) return launch_tile(g128::mx_gemm256_kernel<true, false>, done[2], g128::Lds<true>::TOTAL, p.tiles128, g128::NT, a, stream);
+            return launch_tile(g128::mx_gemm256_kernel<false, false>, done[3], g128::Lds<false>::TOTAL, p.tiles128, g128::NT, a, stream);
+    }
 }
 
 // grouped launch of the tiled kernels: the tile size is chosen for the sum of the groups' tiles with the same round rule as a
