@@ -1,5 +1,5 @@
-"""Small fixed workload for the rocprofv3 passes: N x (reorder_quantize_x + matmul) on the bench shape
-(4096^3, all-MXFP8 activations, w4 weights); `python tools/pmc_target.py mixed` adds the (2048,128,1920) split."""
+"""Small fixed workload for the rocprofv3 passes: 10 x (reorder_quantize_x + matmul) per split on the 4096^3 bench shape, w4
+weights.  `python tools/pmc_target.py [KN,KS,KO ...]` (default: the bench split (0,0,4096))."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -8,7 +8,7 @@ import bench
 from micromix_amd import mixedgemm
 dev = torch.device("cuda:0")
 x, w, idx = [t.to(dev) for t in bench.synth_inputs()]
-splits = [bench.SPLIT] + ([(2048, 128, 1920)] if "mixed" in sys.argv else [])
+splits = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]] or [bench.SPLIT]
 for split in splits:
     b = mixedgemm.reorder_quantize_w4(w, idx, *split)
     for _ in range(10):
