@@ -33,12 +33,6 @@
 #ifndef MM_FP4_KD256
 #define MM_FP4_KD256 1  // fp4 x fp4 segment on 256-deep slabs (whole cache lines per row); 0 = 128-deep slabs like the other segments
 #endif
-#ifndef MM_EPI_DIRECT
-#define MM_EPI_DIRECT 0  // 1: epilogue stores 8 bytes per lane straight from registers (no LDS transpose)
-#endif
-#ifndef MM_NT_STORE
-#define MM_NT_STORE 0
-#endif
 #ifndef MM_DBG
 #define MM_DBG 0  // kernel-developer ablation switches (results are garbage): 1 = no MFMA, 2 = no DMA, 512 = no fragment reads in the loop
 #endif

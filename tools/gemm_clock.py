@@ -11,11 +11,12 @@ x, w, idx = [t.to(dev) for t in bench.synth_inputs()]
 M = N = K = 4096
 out = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
 clk = torch.zeros((4096, 4), dtype=torch.int64, device=dev)
-SPLITS = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]] or [(0, 0, 4096), (4096, 0, 0), (2048, 128, 1920)]
+ROUNDING = "fused" if "fused" in sys.argv else "reference"
+SPLITS = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:] if "," in a] or [(0, 0, 4096), (4096, 0, 0), (2048, 128, 1920)]
 for split in SPLITS:
     b = mixedgemm.reorder_quantize_w4(w, idx, *split)
     a = mixedgemm.reorder_quantize_x(x, idx, *split)
-    f = lambda: mixedgemm.matmul(a[0], b[0], a[1], b[1], a[2], b[2], a[3], b[3], a[4], b[4], a[5], b[5], out=out)
+    f = lambda: mixedgemm.matmul(a[0], b[0], a[1], b[1], a[2], b[2], a[3], b[3], a[4], b[4], a[5], b[5], out=out, rounding=ROUNDING)
     for _ in range(3000): f()          # ~0.2 s of back-to-back launches so that DVFS settles
     torch.cuda.synchronize()
     lib.mm_diag_set_clock_buffer(clk.data_ptr())
@@ -27,4 +28,4 @@ for split in SPLITS:
     start, end = c[:, 2], c[:, 2] + c[:, 3]
     print(f"   start spread {(start.max()-start.min())/100:.2f} us; loop end (rel. first start): median {(start+ticks-start.min()).median()/100:.1f} max {(start+ticks-start.min()).max()/100:.1f} us; "
           f"wave0 stores done: median {(end-start.min()).median()/100:.1f} max {(end-start.min()).max()/100:.1f} us")
-    print(f"{tag:14s} split={split}: loop cycles median {cyc.median():.0f}  loop time median {ticks.median()*10/1000:.1f} us  clock median {ghz.median():.3f} GHz (min {ghz.min():.3f} max {ghz.max():.3f})", flush=True)
+    print(f"{tag:14s} {ROUNDING} split={split}: loop cycles median {cyc.median():.0f}  loop time median {ticks.median()*10/1000:.1f} us  clock median {ghz.median():.3f} GHz (min {ghz.min():.3f} max {ghz.max():.3f})", flush=True)

@@ -1,59 +1,84 @@
-"""Turns a tools/profile.sh output directory into the committed files under profiles/."""
+"""Turns a tools/profile.sh output directory into the files committed under profiles/ (written to gpurun_out/profiles_<tag>/)."""
 import collections, csv, glob, json, os, sys
 out, tag = sys.argv[1], sys.argv[2]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 prof = os.path.join(root, "gpurun_out", f"profiles_{tag}")   # merged back by gpurun; copy into profiles/ afterwards
 os.makedirs(prof, exist_ok=True)
 lines = []
+CMD = "python3 bench.py --steps 20 --warmup 5"
 for f in glob.glob(out + "/trace/*/*_kernel_stats.csv"):
     rows = list(csv.DictReader(open(f)))
     with open(os.path.join(prof, f"{tag}_bench_kernel_stats.csv"), "w") as g:
         w = csv.DictWriter(g, fieldnames=list(rows[0].keys())); w.writeheader(); w.writerows(rows)
-    lines.append("== rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 200 --warmup 50 ==")
+    lines.append(f"== rocprofv3 --kernel-trace --stats -- {CMD}  (every kernel of the run; the GEMM kernel symbol also serves the mixed splits) ==")
     for r in rows:
         lines.append(f"{r['Name'][:70]:70s} calls {r['Calls']:>5s} avg {float(r['AverageNs'])/1e3:8.2f} us min {float(r['MinNs'])/1e3:8.2f} max {float(r['MaxNs'])/1e3:8.2f} {float(r['Percentage']):6.2f}%")
-# bench.py's launches of the w4 GEMM kernel inside the same trace (W = 50, K = 200): 50 warm-up launches, 1 launch that warms the
-# capture stream, 200 of the untimed first graph replay, then launches 252..451 = the timed region (`value`, one hipGraph) and
-# launches 452..651 = the pass with events attached to each dispatch (`roofline.kernel_us`)
+# The headline GEMM (4096^3, split (0,0,4096), w4) = the first uninterrupted run of launches of the 256x256-tile kernel: warm-up,
+# graph capture warm-up, first graph replay, the settle phase, the timed graph replay, the stream-launch pass and, last, the pass
+# with HIP events attached (`roofline.kernel_us`, `steps` launches).  Anything after the next quantizer launch is another split.
 for f in glob.glob(out + "/trace/*/*_kernel_trace.csv"):
-    d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in csv.DictReader(open(f))
-         if "mx_gemm256_kernel<true, false>" in r["Kernel_Name"]]
-    if len(d) >= 651:
-        for name, t in (("timed region (GEMM launches 252..451, hipGraph)", d[251:451]), ("event pass (GEMM launches 452..651)", d[451:651])):
-            lines.append(f"{name}: kernel-trace avg {sum(t)/len(t):.2f} us min {min(t):.2f} max {max(t):.2f}")
+    rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
+    run, started = [], False
+    for r in rows:
+        is_gemm = "g256::mx_gemm256_kernel<true, false>" in r["Kernel_Name"]
+        if is_gemm:
+            started = True
+            run.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+        elif started:
+            break
+    if len(run) >= 60:
+        steps = 20
+        lines.append(f"headline GEMM: {len(run)} consecutive launches in the trace; ALL: avg {sum(run)/len(run):.2f} us min {min(run):.2f} max {max(run):.2f}")
+        for name, t in (("event pass (last 20 launches = roofline.kernel_us)", run[-steps:]), ("stream-launch pass (20 launches before those)", run[-2 * steps:-steps]),
+                        ("timed region (hipGraph replay, 20 launches before those)", run[-3 * steps:-2 * steps]), ("first 26 launches (warm-up, on the clock ramp)", run[:26])):
+            lines.append(f"  {name}: kernel-trace avg {sum(t)/len(t):.2f} us min {min(t):.2f} max {max(t):.2f}")
 bench_line = [l for l in open(out + "/bench_under_rocprof.log") if l.startswith("{")]
 if bench_line:
-    lines.append("== bench.py JSON line of the same (profiled) run; its event-based kernel_us reads ~4 us high under the profiler ==")
+    lines.append("== bench.py JSON line of the same (profiled) run ==")
     lines.append(bench_line[-1].strip())
-agg = collections.defaultdict(list)
-for f in glob.glob(out + "/pmc_*/*/*_counter_collection.csv"):
-    for r in csv.DictReader(open(f)):
-        agg[(r["Kernel_Name"].split("(")[0][-48:], r["Counter_Name"])].append(float(r["Counter_Value"]))
-lines.append("== rocprofv3 --pmc passes -- python3 tools/pmc_target.py (10 x quantize_x + matmul, bench shape) ==")
-stat = {}
-for (k, c), v in sorted(agg.items()):
-    if "gemm" in k or "reorder" in k:
-        lines.append(f"{k:50s} {c:26s} n={len(v):3d} mean={sum(v)/len(v):.6g} min={min(v):.6g} max={max(v):.6g}")
-        kind = "gemm" if "gemm" in k else ("quant" if "<false" in k else "quant_w4")
-        stat[(kind, c)] = sum(v) / len(v)
-g = lambda c: stat.get(("gemm", c))
-if g("FETCH_SIZE") is not None and g("WRITE_SIZE") is not None:
-    fetch_b = 2.0 * g("FETCH_SIZE") * 1024.0     # FETCH_SIZE is in KiB and counts 64 B per 128-B request on gfx950
-    write_b = g("WRITE_SIZE") * 1024.0
-    traffic = {"hbm_bytes_per_launch": int(fetch_b + write_b), "fetch_bytes_corrected": int(fetch_b), "write_bytes": int(write_b),
-               "source": f"profiles/{tag}_summary.txt: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE x2 per MI355X_MICROARCH.md",
-               "l2_hit_rate": (g("TCC_HIT_sum") / (g("TCC_HIT_sum") + g("TCC_MISS_sum"))) if g("TCC_HIT_sum") else None}
-    json.dump(traffic, open(os.path.join(prof, "gemm_traffic.json"), "w"), indent=1)
-    lines.append("== derived ==")
-    lines.append(json.dumps(traffic))
+plain = [l for l in open(out + "/bench_plain.log") if l.startswith("{")] if os.path.exists(out + "/bench_plain.log") else []
+if plain:
+    lines.append(f"== bench.py JSON line of an unprofiled run of the same command on the same box ({CMD}) ==")
+    lines.append(plain[-1].strip())
+traffic = None
+for name in ("fp8", "fp4", "mixed"):
+    d = os.path.join(root, "gpurun_out", f"pmc_{tag}_{name}")
+    agg = collections.defaultdict(list)
+    for f in glob.glob(d + "/*/*/*_counter_collection.csv"):
+        for r in csv.DictReader(open(f)):
+            agg[(r["Kernel_Name"].split("(")[0][-48:], r["Counter_Name"])].append(float(r["Counter_Value"]))
+    if not agg:
+        continue
+    head = open(os.path.join(d, "summary.txt")).readline().strip() if os.path.exists(os.path.join(d, "summary.txt")) else name
+    lines.append(f"== rocprofv3 --pmc passes -- python3 tools/pmc_target.py ({head}; 10 x quantize_x + matmul, 4096^3) ==")
+    stat = {}
+    for (k, c), v in sorted(agg.items()):
+        if "gemm" in k or "reorder" in k:
+            lines.append(f"{k:50s} {c:28s} n={len(v):3d} mean={sum(v)/len(v):.6g} min={min(v):.6g} max={max(v):.6g}")
+            stat[("gemm" if "gemm" in k else "quant", c)] = sum(v) / len(v)
+    g = lambda c: stat.get(("gemm", c))
+    if g("SQ_VALU_MFMA_BUSY_CYCLES") and g("SQ_WAVE_CYCLES"):
+        # SQ_WAVE_CYCLES counts quad-cycles summed over the 2048 waves (two per SIMD); MFMA busy counts cycles summed over the 1024 SIMDs
+        wave_cycles = g("SQ_WAVE_CYCLES") * 4 / 2048
+        lines.append(f"derived: kernel ~{wave_cycles:.0f} shader cycles per wave; matrix pipe busy {g('SQ_VALU_MFMA_BUSY_CYCLES')/1024:.0f} cycles per SIMD "
+                     f"= {g('SQ_VALU_MFMA_BUSY_CYCLES')/1024/wave_cycles:.3f} of the kernel; waves waiting (s_waitcnt/barrier) {g('SQ_WAIT_ANY')/g('SQ_WAVE_CYCLES'):.3f}, "
+                     f"issue stalls {g('SQ_WAIT_INST_ANY')/g('SQ_WAVE_CYCLES'):.3f} of wave time")
+    if g("SQ_LDS_BANK_CONFLICT") is not None and g("SQ_LDS_IDX_ACTIVE"):
+        lines.append(f"derived: LDS bank-conflict cycles {g('SQ_LDS_BANK_CONFLICT'):.0f} = {g('SQ_LDS_BANK_CONFLICT')/g('SQ_LDS_IDX_ACTIVE'):.4f} of the LDS-active cycles")
+    if g("FETCH_SIZE") is not None and g("WRITE_SIZE") is not None:
+        fetch_b = 2.0 * g("FETCH_SIZE") * 1024.0     # FETCH_SIZE is in KiB and counts 64 B per 128-B request on gfx950
+        write_b = g("WRITE_SIZE") * 1024.0
+        t = {"hbm_bytes_per_launch": int(fetch_b + write_b), "fetch_bytes_corrected": int(fetch_b), "write_bytes": int(write_b),
+             "collected": f"profiles/{tag}_summary.txt, split {head}",
+             "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE x2 per MI355X_MICROARCH.md",
+             "l2_hit_rate": (g("TCC_HIT_sum") / (g("TCC_HIT_sum") + g("TCC_MISS_sum"))) if g("TCC_HIT_sum") else None}
+        lines.append("derived: " + json.dumps(t))
+        if name == "fp8":
+            traffic = t
     q = lambda c: stat.get(("quant", c))
-    if q("FETCH_SIZE") is not None and q("WRITE_SIZE") is not None:
-        lines.append(f"quantize_x HBM bytes per launch: {int(2*q('FETCH_SIZE')*1024 + q('WRITE_SIZE')*1024)} (algorithmic 50864128)")
-plain = os.path.join(root, "gpurun_out", "bench_plain.log")
-if os.path.exists(plain):
-    bl = [l for l in open(plain) if l.startswith("{")]
-    if bl:
-        lines.append("== bench.py JSON line of an unprofiled run on the same box ==")
-        lines.append(bl[-1].strip())
+    if name == "fp8" and q("FETCH_SIZE") is not None and q("WRITE_SIZE") is not None:
+        lines.append(f"derived: quantize_x HBM bytes per launch: {int(2*q('FETCH_SIZE')*1024 + q('WRITE_SIZE')*1024)} (algorithmic 50864128)")
+if traffic:
+    json.dump(traffic, open(os.path.join(prof, "gemm_traffic.json"), "w"), indent=1)
 open(os.path.join(prof, f"{tag}_summary.txt"), "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
