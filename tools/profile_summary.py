@@ -24,7 +24,7 @@ for f in glob.glob(out + "/trace/*/*_kernel_trace.csv"):
         if is_gemm:
             started = True
             run.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
-        elif started:
+        elif started and "reorder_quantize" in r["Kernel_Name"]:
             break
     if len(run) >= 60:
         steps = 20
