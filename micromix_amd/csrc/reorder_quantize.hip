@@ -162,9 +162,7 @@ hipError_t launch_reorder_quantize(const void *src, int rows, int K, const int16
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     int blocks = cus * per_cu;
-#if (MM_QDBG & 4)
-    blocks = 2048;
-#endif
+    // (fewer, fatter workgroups that keep their reorder indices for 2 / 4 / 8 rows were measured: 11.1 -> 11.7 / 15.6 / 23.9 us)
     blocks = rows < blocks ? rows : blocks;
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds, stream, (const uint16_t *)src, rows, K, idx, KN, KS, KO, oN,
                        oS, oO, sfN, sfS, sfO);
