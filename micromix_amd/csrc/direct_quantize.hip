@@ -72,7 +72,7 @@ __device__ __forceinline__ uint32_t quantize32(const float (&v)[32], uint8_t *__
             r = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(r, v[8 * i + 6], v[8 * i + 7], scale, 3);
             w[i] = r;
         }
-        *reinterpret_cast<uint4 *>(out) = make_uint4(w[0], w[1], w[2], w[3]);
+        store16<true>(out, w[0], w[1], w[2], w[3]);      // write-through: see store16 (mx_group_convert.h)
     } else {
         f16v lo, hi;
 #pragma unroll

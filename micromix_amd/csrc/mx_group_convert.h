@@ -92,7 +92,9 @@ __device__ MM_TINY_INLINE void quantize_group_tiny(const uint32_t *__restrict__ 
 // v[i] = {element 2i (low half), element 2i+1 (high half)} as bf16 bits; out = RNE(v / scale), scale a normal fp32 power of two.
 // CDNA4 MX converters (v_cvt_scalef32_pk_fp4_bf16 / _pk_fp8_bf16 / _pk32_bf6_bf16: dst = RNE(src / scale), saturating) --
 // tests/test_hw_gpu.py checks them code-for-code against the oracle's encoders for every finite bf16.
-template <int EL>
+// GLOBAL_OUT: `out` is global memory (the stand-alone quantizers), so the fp4 codes may leave by a write-through store; the fused
+// decode kernel quantizes into LDS with the same code and leaves it false.
+template <int EL, bool GLOBAL_OUT = false>
 __device__ __forceinline__ void convert_group(const uint32_t (&v)[16], float scale, uint8_t *__restrict__ out) {
     if constexpr (EL == EL_FP8) {
         uint32_t w[8];
@@ -106,9 +108,8 @@ __device__ __forceinline__ void convert_group(const uint32_t (&v)[16], float sca
             r = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(r, b, scale, true);
             __builtin_memcpy(&w[i], &r, 4);
         }
-        uint4 *o = reinterpret_cast<uint4 *>(out);
-        o[0] = make_uint4(w[0], w[1], w[2], w[3]);
-        o[1] = make_uint4(w[4], w[5], w[6], w[7]);
+        store16<false>(out, w[0], w[1], w[2], w[3]);
+        store16<false>(out + 16, w[4], w[5], w[6], w[7]);
     } else if constexpr (EL == EL_FP4) {
         uint32_t w[4];
 #pragma unroll
@@ -125,7 +126,7 @@ __device__ __forceinline__ void convert_group(const uint32_t (&v)[16], float sca
             r = __builtin_amdgcn_cvt_scalef32_pk_fp4_bf16(r, a, scale, 3);
             w[i] = r;
         }
-        *reinterpret_cast<uint4 *>(out) = make_uint4(w[0], w[1], w[2], w[3]);
+        store16<GLOBAL_OUT>(out, w[0], w[1], w[2], w[3]);
     } else {
         bf32 x;
         __builtin_memcpy(&x, v, 64);
@@ -142,7 +143,7 @@ __device__ __forceinline__ void convert_group(const uint32_t (&v)[16], float sca
 // Conversion uses the CDNA4 MX converters (v_cvt_scalef32_pk_fp4_bf16 / _pk_fp8_bf16 / _pk32_bf6_bf16: dst =
 // RNE(src / scale), saturating) -- tests/test_hw_gpu.py checks them code-for-code against the oracle's encoders for every
 // finite bf16, and tests/test_quantize_gpu.py checks the kernel's bytes.
-template <int EL>
+template <int EL, bool GLOBAL_OUT = false>
 __device__ __forceinline__ uint32_t quantize_group(const uint8_t *__restrict__ row, const uint32_t (&ix)[16],
                                                    uint8_t *__restrict__ out) {
     uint32_t v[16];  // v[i] = {element 2i (low half), element 2i+1 (high half)}
@@ -163,7 +164,7 @@ __device__ __forceinline__ uint32_t quantize_group(const uint8_t *__restrict__ r
         quantize_group_tiny<EL>(v, out);
         return 0u;
     }
-    convert_group<EL>(v, __uint_as_float((uint32_t)(127 + e) << 23), out);  // scale 2^e, a normal fp32
+    convert_group<EL, GLOBAL_OUT>(v, __uint_as_float((uint32_t)(127 + e) << 23), out);  // scale 2^e, a normal fp32
     return (uint32_t)(e + 127);
 }
 

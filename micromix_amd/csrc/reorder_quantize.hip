@@ -91,14 +91,14 @@ __device__ __forceinline__ void reorder_quantize_body(const uint16_t *__restrict
             uint32_t byte;
             uint8_t *sf;
             if (seg == 0) {
-                byte = quantize_group<EL_FP4>(row, ix, oN + (size_t)r * (KN >> 1) + j * 16);
+                byte = quantize_group<EL_FP4, true>(row, ix, oN + (size_t)r * (KN >> 1) + j * 16);
                 sf = sfN;
             } else if (seg == 1) {
-                if constexpr (W4) byte = quantize_group<EL_FP4>(row, ix, oS + (size_t)r * (KS >> 1) + j * 16);
+                if constexpr (W4) byte = quantize_group<EL_FP4, true>(row, ix, oS + (size_t)r * (KS >> 1) + j * 16);
                 else byte = quantize_group<EL_FP6>(row, ix, oS + (size_t)r * (KS / 4 * 3) + j * 24);
                 sf = sfS;
             } else {
-                if constexpr (W4) byte = quantize_group<EL_FP4>(row, ix, oO + (size_t)r * (KO >> 1) + j * 16);
+                if constexpr (W4) byte = quantize_group<EL_FP4, true>(row, ix, oO + (size_t)r * (KO >> 1) + j * 16);
                 else byte = quantize_group<EL_FP8>(row, ix, oO + (size_t)r * KO + j * 32);
                 sf = sfO;
             }

@@ -57,9 +57,9 @@ __device__ __forceinline__ uint32_t rms_quantize_group(const uint8_t *__restrict
             t = t + f2{__builtin_copysignf(0.5f, t[0]), __builtin_copysignf(0.5f, t[1])};
             v[i] = pack_bf16x2(__builtin_truncf(t[0]), __builtin_truncf(t[1]));
         }
-        convert_group<EL>(v, 1.0f, out);
+        convert_group<EL, true>(v, 1.0f, out);
     } else {
-        convert_group<EL>(v, __uint_as_float((uint32_t)(127 + e) << 23), out);
+        convert_group<EL, true>(v, __uint_as_float((uint32_t)(127 + e) << 23), out);
     }
     return (uint32_t)(e + 127);
 }

@@ -20,12 +20,17 @@ for split in SPLITS:
     for _ in range(3000): f()          # ~0.2 s of back-to-back launches so that DVFS settles
     torch.cuda.synchronize()
     lib.mm_diag_set_clock_buffer(clk.data_ptr())
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); e1.record(); torch.cuda.synchronize()
+    lib.mm_diag_set_kernel_events(e0.cuda_event, e1.cuda_event)
     f(); torch.cuda.synchronize()
+    lib.mm_diag_set_kernel_events(None, None)
     lib.mm_diag_set_clock_buffer(None)
+    kernel_us = e0.elapsed_time(e1) * 1e3
     c = clk[:256].cpu().double()
     cyc, ticks = c[:, 0], c[:, 1]
     ghz = (cyc / ticks * 0.1)
     start, end = c[:, 2], c[:, 2] + c[:, 3]
     print(f"   start spread {(start.max()-start.min())/100:.2f} us; loop end (rel. first start): median {(start+ticks-start.min()).median()/100:.1f} max {(start+ticks-start.min()).max()/100:.1f} us; "
-          f"wave0 stores done: median {(end-start.min()).median()/100:.1f} max {(end-start.min()).max()/100:.1f} us")
+          f"wave0 stores done: median {(end-start.min()).median()/100:.1f} max {(end-start.min()).max()/100:.1f} us; kernel (dispatch events) {kernel_us:.1f} us")
     print(f"{tag:14s} {ROUNDING} split={split}: loop cycles median {cyc.median():.0f}  loop time median {ticks.median()*10/1000:.1f} us  clock median {ghz.median():.3f} GHz (min {ghz.min():.3f} max {ghz.max():.3f})", flush=True)
