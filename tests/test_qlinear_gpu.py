@@ -124,3 +124,30 @@ def test_call_plan_follows_replaced_weights(dev):
     assert torch.equal(a(x), yb)
     x2 = torch.randn((1, 40, k), generator=g).to(torch.bfloat16).to(dev)
     assert torch.equal(a(x2), b(x2))
+
+
+@pytest.mark.parametrize("m", (4, 200))
+def test_fused_rounding_option(dev, m):
+    """QLinearLayer(rounding="fused"): one bf16 rounding instead of the reference's per-segment chain, on every forward path
+    (fused decode kernel for m <= 8, quantize + GEMM otherwise, tuple input), against the oracle's fused chain"""
+    import torch
+    from conftest import u8
+    from gemm_check import check_gemm
+    g = torch.Generator().manual_seed(21)
+    k, n, split = 1024, 384, (512, 128, 384)
+    idx = torch.randperm(k, generator=g)
+    lin = torch.nn.Linear(k, n, bias=True, dtype=torch.bfloat16)
+    with torch.no_grad():
+        lin.weight.copy_((torch.randn((n, k), generator=g) * 0.05).to(torch.bfloat16))
+        lin.bias.copy_(torch.randn((n,), generator=g).to(torch.bfloat16))
+    ref_layer = QLinearLayer(lin.to(dev), p8_num=split[2], p6_num=split[1], reorder_index=idx)
+    layer = QLinearLayer(lin.to(dev), p8_num=split[2], p6_num=split[1], reorder_index=idx, rounding="fused")
+    x = torch.randn((1, m, k), generator=g).to(torch.bfloat16).to(dev)
+    y = layer(x)
+    qx = o.reorder_quantize(bits_from_t(x[0]), u8(layer.reorder_index), *split, "x")
+    qw = [u8(t) for t in (layer.BN, layer.BS, layer.BO, layer.SFBN, layer.SFBS, layer.SFBO)]
+    check_gemm(bits_from_t(y[0]), qx, qw, "fused", label=f"fused rounding m={m}", bias_bits=bits_from_t(layer.bias), strict=m > 8)
+    assert torch.equal(layer(layer.quantize_input(x)), y)
+    assert not torch.equal(ref_layer(x), y) or m < 8          # the two chains differ somewhere on 200 x 384 outputs
+    with pytest.raises(ValueError):
+        QLinearLayer(lin.to(dev), p8_num=split[2], p6_num=split[1], reorder_index=idx, rounding="nearest")

@@ -40,3 +40,40 @@ def test_sharded_sum_equals_unsharded(dev, world, split):
     err = (total - full).abs()
     assert float(err.max()) <= (world + 1) * 2.0 ** -9 * float(full.abs().max()) + 1e-3
     assert float(torch.linalg.norm(err) / torch.linalg.norm(full)) < 2.0 ** -8 * world ** 0.5
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_megatron_mlp_partials_sum_to_unsharded_chain(dev, world):
+    """TPMLP (gate/up column-parallel -> activate_quantize_x on the local slice -> down row-parallel) with the HIP kernels, every
+    rank in turn on one GPU: the fp32 sum of the partials against the unsharded GPU chain (gate, up, activate_quantize_x over the
+    full intermediate width, down), and each rank's quantized slice byte-for-byte against the corresponding columns of the
+    unsharded quantization (shards are 128-aligned, so every 32-block keeps its scale)."""
+    import torch
+    rng = np.random.default_rng(world + 30)
+    m, hid, inter = 96, 512, 2048
+    in_split, down_split = (256, 128, 128), (1024, 512, 512)
+    x = t_from_bits(make_inputs(rng, m, hid), dev)
+    wg = t_from_bits(make_inputs(rng, inter, hid, "weight"), dev)
+    wu = t_from_bits(make_inputs(rng, inter, hid, "weight"), dev)
+    wd = t_from_bits(make_inputs(rng, hid, inter, "weight"), dev)
+    idx = torch.from_numpy(rng.permutation(hid).astype(np.int16)).to(dev)
+    mm = lambda a, b, **kw: mixedgemm.matmul(a[0], b[0], a[1], b[1], a[2], b[2], a[3], b[3], a[4], b[4], a[5], b[5], **kw)
+    qx = mixedgemm.reorder_quantize_x(x, idx, *in_split)
+    g = mm(qx, mixedgemm.reorder_quantize_w4(wg, idx, *in_split))
+    u = mm(qx, mixedgemm.reorder_quantize_w4(wu, idx, *in_split))
+    qh = mixedgemm.activate_quantize_x(g, u, *down_split)
+    full = mm(qh, mixedgemm.downproj_quantize_w4(wd, *down_split), rounding="fused").float()
+    total = torch.zeros((m, hid), dtype=torch.float32, device=dev)
+    covered = 0
+    for r in range(world):
+        mlp = tp.TPMLP(wg, wu, wd, idx, in_split, down_split, rank=r, world=world)
+        covered += int(mlp.positions.numel())
+        part = mlp.partial(mlp.quantize_x(x))
+        total += part.float()
+        # the local gate slice equals the corresponding columns of the unsharded gate output, bit for bit
+        gl = mlp.ops.matmul(qx, mlp.packed_gate, rounding="reference")
+        assert torch.equal(gl, g[:, mlp.positions.to(dev)])
+    assert covered == inter
+    err = (total - full).abs()
+    assert float(err.max()) <= (world + 1) * 2.0 ** -9 * float(full.abs().max()) + 1e-3
+    assert float(torch.linalg.norm(err) / torch.linalg.norm(full)) < 2.0 ** -8 * world ** 0.5
