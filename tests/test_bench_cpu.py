@@ -1,0 +1,44 @@
+"""CPU tests of the measurement harness: the per-precision roofline formula of bench.py, its synthetic
+inputs, and the kernel-dispatch description the bench line quotes (mm_matmul_describe, no device work)."""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from micromix_amd import _lib  # noqa: E402
+
+
+def test_roofline_time_matches_survey_reference_points():
+    # 4096^3 = 137.4 GFLOP -> t* = 27.3 us at the fp8 rate, 13.7 us at the fp4 / fp6 rate
+    assert bench.roofline_time_s(4096, 4096, (0, 0, 4096)) * 1e6 == pytest.approx(27.3, abs=0.05)
+    assert bench.roofline_time_s(4096, 4096, (4096, 0, 0)) * 1e6 == pytest.approx(13.65, abs=0.05)
+    assert bench.roofline_time_s(4096, 4096, (0, 4096, 0)) * 1e6 == pytest.approx(13.65, abs=0.05)
+    # mixed: segments add; fp6 activations run at the fp4 rate on CDNA4
+    t = bench.roofline_time_s(4096, 4096, (2048, 128, 1920)) * 1e6
+    assert t == pytest.approx((2048 + 128) / 4096 * 13.65 + 1920 / 4096 * 27.3, abs=0.05)
+    assert bench.roofline_time_s(4096, 4096, (12288, 1024, 1024)) * 1e6 == pytest.approx(51.2, abs=0.1)
+
+
+def test_synthetic_inputs_are_reproducible_and_shaped():
+    import torch
+    x, w, idx = bench.synth_inputs(seed=0, m=64, n=32, k=256)
+    x2, w2, idx2 = bench.synth_inputs(seed=0, m=64, n=32, k=256)
+    assert x.shape == (64, 256) and w.shape == (32, 256) and idx.dtype == torch.int16
+    assert torch.equal(x, x2) and torch.equal(w, w2) and torch.equal(idx, idx2)
+    assert sorted(idx.tolist()) == list(range(256))          # a permutation: ascending mean |x| (reorder_indices.py:64-69)
+    mean = x.float().abs().mean(0)
+    assert set(idx[-2:].tolist()) == set(torch.topk(mean, 2).indices.tolist())   # the x20 outlier channels land in the fp8 segment
+
+
+def test_matmul_describe_names_the_dispatch():
+    lib = _lib.load()
+    d = lambda *a: lib.mm_matmul_describe(*a).decode()
+    assert "g256" in d(4096, 4096, 0, 0, 4096, 1, 0, 0) and "256 workgroups" in d(4096, 4096, 0, 0, 4096, 1, 0, 0)
+    assert "last 8 tile columns" in d(4096, 14336, 0, 0, 4096, 1, 0, 0)        # 896 tiles = 3.5 rounds: tail balancing
+    assert "skinny" in d(16, 4096, 0, 0, 4096, 1, 0, 0)
+    assert "<false,false>" in d(4096, 4096, 0, 0, 4096, 0, 0, 0)               # matching-precision weights
+    assert d(0, 4096, 0, 0, 4096, 1, 0, 0) == "none" and d(4096, 4096, 100, 0, 0, 1, 0, 0) == "none"
+    assert "split-K" in d(192, 256, 12288, 1024, 1024, 1, _lib.MM_SPLIT_K_ALWAYS, 1 << 30)
