@@ -33,9 +33,6 @@
 #ifndef MM_FP4_KD256
 #define MM_FP4_KD256 1  // fp4 x fp4 segment on 256-deep slabs (whole cache lines per row); 0 = 128-deep slabs like the other segments
 #endif
-#ifndef MM_MAX_STAGES
-#define MM_MAX_STAGES 3   // upper bound on the DMA pipeline depth (stages of one slab each); 4 and 6 measured on the 128-row tiles: 0 ... +5 % time
-#endif
 #ifndef MM_DBG
 #define MM_DBG 0  // kernel-developer ablation switches (results are garbage): 1 = no MFMA, 2 = no DMA, 512 = no fragment reads in the loop
 #endif
