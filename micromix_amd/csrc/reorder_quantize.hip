@@ -162,7 +162,9 @@ hipError_t launch_reorder_quantize(const void *src, int rows, int K, const int16
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     int blocks = cus * per_cu;
-    // (fewer, fatter workgroups that keep their reorder indices for 2 / 4 / 8 rows were measured: 11.1 -> 11.7 / 15.6 / 23.9 us)
+    // (fewer, fatter workgroups that keep their reorder indices for 2 / 4 / 8 rows were measured: 11.1 -> 11.7 / 15.6 / 23.9 us;
+    // one row per workgroup with the occupancy limited to 12 / 8 / 4 workgroups per CU, so that rounds of workgroups overlap
+    // their load / gather / store phases: 11.3 / 11.4 / 13.7 us)
     blocks = rows < blocks ? rows : blocks;
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds, stream, (const uint16_t *)src, rows, K, idx, KN, KS, KO, oN,
                        oS, oO, sfN, sfS, sfO);
