@@ -14,7 +14,7 @@ def pytest_configure(config):
     # Test-infrastructure convenience only: the product never builds or falls back by itself (micromix_amd._lib.load() raises
     # when the library is absent).  If the built library did not travel with the checkout, build it once here.
     from micromix_amd import _lib, build
-    if not os.path.exists(_lib.LIB_PATH):
+    if not (os.path.exists(_lib.LIB_PATH) and os.path.exists(_lib.DIAG_LIB_PATH)):
         try:
             build.build(verbose=False)
         except Exception as e:  # the tests that need the library will fail with the loader's message
