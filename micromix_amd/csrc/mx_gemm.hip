@@ -22,8 +22,9 @@
 //
 // Kernels by token count M:
 //  * M <= 64 : mx_gemm_skinny.hip -- weight-streaming, 32 features per workgroup, K split over the 8 waves
-//  * M  > 64 : mx_gemm256.hip     -- LDS-DMA pipelined 256x256 tiles (>= 192 of them) or 128x256 tiles, the latter
-//                                    with split-K through a caller-provided workspace when there are few tiles
+//  * M  > 64 : mx_gemm256.hip     -- LDS-DMA pipelined 256x256 tiles when they fill the chip, else 128x256 / 128x128 tiles,
+//                                    64x128 / 64x64 tiles with loader and compute waves for the smallest launches, or split-K
+//                                    through a caller-provided workspace (plan_tiles / plan_splits, fitted to measurements)
 #include "mx_common.h"
 #include "mx_kernels.h"
 

@@ -1,4 +1,7 @@
-// 256x256-tile fused three-segment MX GEMM for gfx950 -- the large-M path of mm_matmul.
+// Tiled fused three-segment MX GEMM for gfx950 -- the M > 64 path of mm_matmul: 256x256 tiles when they fill the chip, 128x256 /
+// 128x128 tiles (same 8-wave body) or 64x128 / 64x64 tiles (4 compute + 4 loader waves) for launches with fewer tiles, split-K
+// through a caller-provided workspace for the fewest; plan_tiles() chooses, mm_matmul_describe() reports the choice.
+// The notes below are about the 256x256 tile; mx_gemm_tile.inc documents the body and the 64-row pipeline.
 //
 // Arithmetic and reference citations: see mx_gemm.hip (gemm.cu:26-78, w4a4.cu, w4a6.cu, w4a8.cu, w6a6.cu,
 // w8a8.cu).  Machine mapping, chosen from measurements on MI355X
@@ -50,26 +53,80 @@ namespace mm {
 #endif
 
 #define MM_NS g256
+#define MM_MAX_STAGES 3
+#define MM_LDS_BUDGET (160 * 1024)
+#define MM_WM 4
 #define MM_TM 2
 #define MM_TN 4
+#define MM_ACC MM_ACC_CLOBBER
 #include "mx_gemm_tile.inc"
 #undef MM_NS
+#undef MM_WM
 #undef MM_TM
 #undef MM_TN
+#undef MM_ACC
+#undef MM_MAX_STAGES
+#undef MM_LDS_BUDGET
 #define MM_NS g128
+#define MM_MAX_STAGES 3
+#define MM_LDS_BUDGET (160 * 1024)
+#define MM_WM 4
 #define MM_TM 1
 #define MM_TN 4
+#define MM_ACC MM_ACC_CLOBBER
 #include "mx_gemm_tile.inc"
 #undef MM_NS
+#undef MM_WM
 #undef MM_TM
 #undef MM_TN
+#undef MM_ACC
+#undef MM_MAX_STAGES
+#undef MM_LDS_BUDGET
 #define MM_NS g64
+#define MM_MAX_STAGES 3
+#define MM_LDS_BUDGET (160 * 1024)
+#define MM_WM 4
 #define MM_TM 1
 #define MM_TN 2
+#define MM_ACC MM_ACC_CLOBBER
 #include "mx_gemm_tile.inc"
 #undef MM_NS
+#undef MM_WM
 #undef MM_TM
 #undef MM_TN
+#undef MM_ACC
+#undef MM_MAX_STAGES
+#undef MM_LDS_BUDGET
+#define MM_NS g32
+#define MM_MAX_STAGES 3
+#define MM_LDS_BUDGET (160 * 1024)
+#define MM_WM 2
+#define MM_TM 1
+#define MM_TN 2
+#define MM_ACC MM_ACC_CLOBBER32
+#include "mx_gemm_tile.inc"
+#undef MM_NS
+#undef MM_WM
+#undef MM_TM
+#undef MM_TN
+#undef MM_ACC
+#undef MM_MAX_STAGES
+#undef MM_LDS_BUDGET
+#define MM_NS g32n
+#define MM_MAX_STAGES 3
+#define MM_LDS_BUDGET (160 * 1024)
+#define MM_WM 2
+#define MM_TM 1
+#define MM_TN 1
+#define MM_ACC MM_ACC_CLOBBER32
+#include "mx_gemm_tile.inc"
+#undef MM_NS
+#undef MM_WM
+#undef MM_TM
+#undef MM_TN
+#undef MM_ACC
+#undef MM_MAX_STAGES
+#undef MM_LDS_BUDGET
 
 
 // ---------------------------------------------------------------------------------------------------------
@@ -134,8 +191,8 @@ static int env_int(const char *name, int dflt) {
 // 128-deep slab in ~0.7 us (DMA-latency bound), and every split adds tiles * 128 KiB of fp32 partial sums that are
 // written and read back at ~4 TB/s (0.064 us per tile and split), plus ~5 us for the second launch:
 //     t(S) = 0.7 * slabs / S + 0.064 * tiles * S (+ 5)   ->   S* = 3.3 * sqrt(slabs / tiles)
-// Split only when that beats the unsplit launch (128 x 128 tiles at these tile counts, ~0.5 us per slab) by 15 %.  `force` (MM_SPLIT_K_ALWAYS, tests and tuning) skips the
-// model.  MICROMIX_SPLITK=0 disables splitting, =S pins the split count.
+// Split only when that beats the unsplit launch (the tile plan_tiles would pick at these tile counts, see below) by a margin.
+// `force` (MM_SPLIT_K_ALWAYS, tests and tuning) skips the model.  MICROMIX_SPLITK=0 disables splitting, =S pins the split count.
 static int plan_splits(int M, int N, const int K[3], bool force, int first[4]) {
     static const int pinned = env_int("MICROMIX_SPLITK", -1);
     if (pinned == 0 || M <= 64) return 0;
@@ -157,8 +214,15 @@ static int plan_splits(int M, int N, const int K[3], bool force, int first[4]) {
         S = (int)(3.3f * sqrtf((float)total / (float)tiles) + 0.5f);
         S = S < nonempty ? nonempty : S;
         S = S > cap ? cap : S;
-        const float unsplit = 0.5f * total, split = 0.7f * total / S + 0.064f * tiles * S + 5.0f;   // unsplit: 128 x 128 tiles, ~0.5 us per slab
-        if (S < 2 || split > 0.85f * unsplit) return 0;
+        // unsplit: 128 x 128 tiles walk a slab in ~0.5 us; the 4-wave tiles (when plan_tiles would pick them: one round of
+        // workgroups) in ~0.32 us (64 x 64) / ~0.36 us (64 x 128).  Margins fitted to tools/mid_m_sweep.py (down_proj, K = 14336:
+        // split at M <= 384, unsplit 64 x 128 tiles at M = 512; k/v and q/o at K = 4096: never split).
+        const int t32n = ((M + 63) / 64) * ((N + 63) / 64), t32 = ((M + 63) / 64) * ((N + 127) / 128);
+        const int t64 = ((M + 127) / 128) * ((N + 127) / 128);
+        const bool g32n_fits = t32n <= 256, g32_fits = !g32n_fits && t32 <= 256 && 2 * t64 <= 256;
+        const float unsplit = (g32n_fits ? 0.32f : g32_fits ? 0.36f : 0.5f) * total, margin = g32_fits ? 0.95f : 0.85f;
+        const float split = 0.7f * total / S + 0.064f * tiles * S + 5.0f;
+        if (S < 2 || split > margin * unsplit) return 0;
     }
     S = S > cap ? cap : S;
     if (S < 2 || S < nonempty) return 0;
@@ -208,10 +272,10 @@ static hipError_t launch_tile(KernelT kern, DynamicLdsOnce &attr, int lds_bytes,
 }
 
 // Which kernel(s) a problem runs on: decided once here, used by the launcher and by mm_matmul_describe.
-enum TileKind { TK_SPLITK, TK_G64, TK_G256_TAIL, TK_G256, TK_G128 };
+enum TileKind { TK_SPLITK, TK_G64, TK_G256_TAIL, TK_G256, TK_G128, TK_G32, TK_G32N };
 struct TilePlan {
     TileKind kind;
-    int tn, tiles256, tiles128, tiles64, tm256, tm128, tail_cols;
+    int tn, tiles256, tiles128, tiles64, tiles32, tiles32n, tm256, tm128, tail_cols;
     int splits, split_first[4];
 };
 
@@ -223,6 +287,8 @@ static TilePlan plan_tiles(int M, int N, const int K[3], bool have_ws, size_t ws
     p.tiles256 = p.tm256 * p.tn;
     p.tiles128 = p.tm128 * p.tn;
     p.tiles64 = p.tm128 * ((N + 127) / 128);
+    p.tiles32 = ((M + 63) / 64) * ((N + 127) / 128);
+    p.tiles32n = ((M + 63) / 64) * ((N + 63) / 64);
     if (have_ws) {
         p.splits = plan_splits(M, N, K, force_split, p.split_first);
         if (p.splits && (size_t)p.tiles128 * p.splits * SPLIT_WG_FLOATS * sizeof(float) <= ws_bytes) {
@@ -234,6 +300,21 @@ static TilePlan plan_tiles(int M, int N, const int K[3], bool have_ws, size_t ws
     static const int force = env_int("MICROMIX_GEMM_TILE", 0);   // kernel-developer override: 256, 128 or 64
     static const int tail_split = env_int("MICROMIX_GEMM_TAIL", 1);
     const int cus = device_cus();
+    if (force == 32 || force == 33) {
+        p.kind = force == 32 ? TK_G32 : TK_G32N;
+        return p;
+    }
+    // Fewer than a CU's worth of 128-row tiles: the 4-wave tiles (64 rows, loader / compute waves, see mx_gemm_tile.inc) fill more
+    // CUs.  64 x 64 while those fit one round of workgroups (M <= 256 at N = 4096: 11-12 us against 17 us at K = 4096), 64 x 128
+    // while THEY fit one round and the 128 x 128 tiles would leave half of the CUs idle (M = 512 at N = 4096: 14.7 against 17.7).
+    if (force == 0 && p.tiles32n <= cus) {
+        p.kind = TK_G32N;
+        return p;
+    }
+    if (force == 0 && p.tiles32 <= cus && 2 * p.tiles64 <= cus) {
+        p.kind = TK_G32;
+        return p;
+    }
     // One workgroup fits per CU, so a launch runs in rounds of `cus` tiles.  256-row tiles move the fewest L2->LDS bytes per
     // flop; a round of 128-row tiles takes ~0.62 of a round of 256-row tiles (measured).  So 128-row tiles pay exactly when
     // they still fit in ONE round (tiles128 <= cus, i.e. at most half of the CUs would get a 256-row tile): M=2048, N=4096
@@ -265,6 +346,8 @@ const char *describe_mx_gemm256(int M, int N, const int K[3], bool w4, size_t ws
     switch (p.kind) {
         case TK_SPLITK: snprintf(buf, sizeof(buf), "mm::g128::mx_gemm256_kernel<%s,true> x %d workgroups (128x256 tiles, split-K %d) + mm::splitk_reduce_kernel", w, p.tiles128 * p.splits, p.splits); break;
         case TK_G64: snprintf(buf, sizeof(buf), "mm::g64::mx_gemm256_kernel<%s,false> x %d workgroups (128x128 tiles)", w, p.tiles64); break;
+        case TK_G32: snprintf(buf, sizeof(buf), "mm::g32::mx_gemm256_kernel<%s,false> x %d workgroups (64x128 tiles)", w, p.tiles32); break;
+        case TK_G32N: snprintf(buf, sizeof(buf), "mm::g32n::mx_gemm256_kernel<%s,false> x %d workgroups (64x64 tiles)", w, p.tiles32n); break;
         case TK_G256_TAIL: snprintf(buf, sizeof(buf), "mm::g256::mx_gemm256_kernel<%s,false> x %d workgroups (256x256 tiles) + mm::g128::mx_gemm256_kernel<%s,false> x %d (last %d tile columns as 128x256 tiles)", w, p.tm256 * (p.tn - p.tail_cols), w, p.tm128 * p.tail_cols, p.tail_cols); break;
         case TK_G256: snprintf(buf, sizeof(buf), "mm::g256::mx_gemm256_kernel<%s,false> x %d workgroups (256x256 tiles)", w, p.tiles256); break;
         default: snprintf(buf, sizeof(buf), "mm::g128::mx_gemm256_kernel<%s,false> x %d workgroups (128x256 tiles)", w, p.tiles128); break;
@@ -273,7 +356,7 @@ const char *describe_mx_gemm256(int M, int N, const int K[3], bool w4, size_t ws
 }
 
 hipError_t launch_mx_gemm256(const GemmArgs &a, bool w4, hipStream_t stream) {
-    static DynamicLdsOnce done[8];
+    static DynamicLdsOnce done[12];
     const TilePlan p = plan_tiles(a.M, a.N, a.K, a.ws != nullptr, a.ws_bytes, a.force_split != 0);
     switch (p.kind) {
         case TK_SPLITK: {
@@ -290,6 +373,12 @@ hipError_t launch_mx_gemm256(const GemmArgs &a, bool w4, hipStream_t stream) {
         case TK_G64:
             if (w4) return launch_tile(g64::mx_gemm256_kernel<true, false>, done[6], g64::Lds<true>::TOTAL, p.tiles64, g64::NT, a, stream);
             return launch_tile(g64::mx_gemm256_kernel<false, false>, done[7], g64::Lds<false>::TOTAL, p.tiles64, g64::NT, a, stream);
+        case TK_G32:
+            if (w4) return launch_tile(g32::mx_gemm256_kernel<true, false>, done[8], g32::Lds<true>::TOTAL, p.tiles32, g32::NTHREADS, a, stream);
+            return launch_tile(g32::mx_gemm256_kernel<false, false>, done[9], g32::Lds<false>::TOTAL, p.tiles32, g32::NTHREADS, a, stream);
+        case TK_G32N:
+            if (w4) return launch_tile(g32n::mx_gemm256_kernel<true, false>, done[10], g32n::Lds<true>::TOTAL, p.tiles32n, g32n::NTHREADS, a, stream);
+            return launch_tile(g32n::mx_gemm256_kernel<false, false>, done[11], g32n::Lds<false>::TOTAL, p.tiles32n, g32n::NTHREADS, a, stream);
         case TK_G256_TAIL: {
             const int c = p.tail_cols;
             GemmArgs lo = a, hi = a;
@@ -323,9 +412,11 @@ hipError_t launch_mx_gemm256_grouped(GroupedTileArgs &ga, bool w4, hipStream_t s
         for (int i = 0; i < ga.ngroups; ++i) t += ((ga.g[i].M + bm - 1) / bm) * ((N + bn - 1) / bn);
         return t;
     };
-    const int t128 = tiles(128, 256), t64 = tiles(128, 128);
+    const int t128 = tiles(128, 256), t64 = tiles(128, 128), t32 = tiles(64, 128), t32n = tiles(64, 64);
     int bm, bn;
-    if (2 * t128 <= cus && t64 <= cus) { bm = 128; bn = 128; }
+    if (t32n <= cus) { bm = 64; bn = 64; }                         // the 4-wave tiles, as for a single problem (plan_tiles)
+    else if (t32 <= cus && 2 * t64 <= cus) { bm = 64; bn = 128; }
+    else if (2 * t128 <= cus && t64 <= cus) { bm = 128; bn = 128; }
     else if (t128 <= cus) { bm = 128; bn = 256; }
     else { bm = 256; bn = 256; }
     ga.first_block[0] = 0;
@@ -333,12 +424,16 @@ hipError_t launch_mx_gemm256_grouped(GroupedTileArgs &ga, bool w4, hipStream_t s
         ga.first_block[i + 1] = ga.first_block[i] + ((ga.g[i].M + bm - 1) / bm) * ((N + bn - 1) / bn);
     for (int i = ga.ngroups + 1; i <= MM_MAX_GROUPS; ++i) ga.first_block[i] = ga.first_block[ga.ngroups];
     const int total = ga.first_block[ga.ngroups];
-    static DynamicLdsOnce done[6];
+    static DynamicLdsOnce done[10];
     auto go = [&](auto kern, DynamicLdsOnce &d, int lds, int threads) -> hipError_t {
         if (hipError_t e = d.ensure(reinterpret_cast<const void *>(kern), lds); e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, dim3(total), dim3(threads), lds, stream, ga);
         return hipGetLastError();
     };
+    if (bm == 64 && bn == 64) return w4 ? go(g32n::mx_gemm256_grouped_kernel<true>, done[6], g32n::Lds<true>::TOTAL, g32n::NTHREADS)
+                                        : go(g32n::mx_gemm256_grouped_kernel<false>, done[7], g32n::Lds<false>::TOTAL, g32n::NTHREADS);
+    if (bm == 64) return w4 ? go(g32::mx_gemm256_grouped_kernel<true>, done[8], g32::Lds<true>::TOTAL, g32::NTHREADS)
+                            : go(g32::mx_gemm256_grouped_kernel<false>, done[9], g32::Lds<false>::TOTAL, g32::NTHREADS);
     if (bm == 256) return w4 ? go(g256::mx_gemm256_grouped_kernel<true>, done[0], g256::Lds<true>::TOTAL, g256::NT)
                              : go(g256::mx_gemm256_grouped_kernel<false>, done[1], g256::Lds<false>::TOTAL, g256::NT);
     if (bn == 256) return w4 ? go(g128::mx_gemm256_grouped_kernel<true>, done[2], g128::Lds<true>::TOTAL, g128::NT)

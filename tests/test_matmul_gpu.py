@@ -213,6 +213,36 @@ def test_full_size_properties(dev):
             check_gemm(bits_from_t(d1)[rows], qx, qw, "reference", label=f"4096^3 {split}")
 
 
+# one problem per tile kernel of mx_gemm256.hip (the dispatch is asserted, so a change of plan_tiles cannot silently drop one):
+# ragged M and N, all three segments, both weight modes; oracle on a row sample over every column
+TILE_KERNELS = [
+    ("g32n", "64x64", 250, 4000), ("g32", "64x128", 500, 4090), ("g64", "128x128", 700, 4090),
+    ("g128", "128x256", 1500, 4000), ("g256", "256x256", 4000, 4090),
+]
+
+
+@pytest.mark.parametrize("wmode", ("w4", "w"))
+@pytest.mark.parametrize("ns,tile,M,N", TILE_KERNELS, ids=[t[0] for t in TILE_KERNELS])
+def test_every_tile_kernel(dev, ns, tile, M, N, wmode):
+    import torch
+    from micromix_amd import _lib
+    K, split = 640, (256, 128, 256)
+    desc = _lib.load().mm_matmul_describe(M, N, *split, 1 if wmode == "w4" else 0, 0, 0).decode()
+    assert f"mm::{ns}::" in desc and f"({tile} tiles" in desc, desc
+    rng = np.random.default_rng(M + N)
+    xb = make_inputs(rng, M, K)
+    wb = make_inputs(rng, N, K, "weight")
+    idx = rng.permutation(K).astype(np.int16)
+    x, w, tidx = t_from_bits(xb, dev), t_from_bits(wb, dev), torch.from_numpy(idx).to(dev)
+    a = mixedgemm.reorder_quantize_x(x, tidx, *split)
+    b = (mixedgemm.reorder_quantize_w4 if wmode == "w4" else mixedgemm.reorder_quantize_w)(w, tidx, *split)
+    for rounding in ("reference", "fused"):
+        d = mixedgemm.matmul(a[0], b[0], a[1], b[1], a[2], b[2], a[3], b[3], a[4], b[4], a[5], b[5], rounding=rounding, split_k=False)
+        rows = np.unique(np.concatenate([rng.choice(M, 24, replace=False), [0, 63, 64, 127, 128, M - 1]]))
+        qx = o.reorder_quantize(xb[rows], idx, *split, "x")
+        check_gemm(bits_from_t(d)[rows], qx, [u8(t) for t in b], rounding, label=f"{ns} {M}x{N} {wmode} {rounding}")
+
+
 def test_tail_balanced_launch(dev):
     """more 256x256 tiles than CUs with a small remainder: the launcher runs the last tile columns as 128-row tiles (two
     launches).  M=2048, N=8448 -> 8 x 33 = 264 tiles = 256 + one column.  Oracle on a row sample, every column."""

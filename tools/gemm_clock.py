@@ -8,7 +8,9 @@ from micromix_amd import _lib, mixedgemm
 lib = _lib.load(); dev = torch.device("cuda:0")
 tag = os.path.basename(os.environ.get("MICROMIX_HIP_LIB", "default"))
 x, w, idx = [t.to(dev) for t in bench.synth_inputs()]
-M = N = K = 4096
+N = K = 4096
+M = next((int(a[2:]) for a in sys.argv[1:] if a.startswith("M=")), 4096)   # M=<rows>: the first rows of the bench activations
+x = x[:M].contiguous()
 out = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
 clk = torch.zeros((4096, 4), dtype=torch.int64, device=dev)
 ROUNDING = "fused" if "fused" in sys.argv else "reference"
@@ -17,6 +19,7 @@ for split in SPLITS:
     b = mixedgemm.reorder_quantize_w4(w, idx, *split)
     a = mixedgemm.reorder_quantize_x(x, idx, *split)
     f = lambda: mixedgemm.matmul(a[0], b[0], a[1], b[1], a[2], b[2], a[3], b[3], a[4], b[4], a[5], b[5], out=out, rounding=ROUNDING)
+    clk.zero_()
     for _ in range(3000): f()          # ~0.2 s of back-to-back launches so that DVFS settles
     torch.cuda.synchronize()
     lib.mm_diag_set_clock_buffer(clk.data_ptr())
@@ -27,10 +30,11 @@ for split in SPLITS:
     lib.mm_diag_set_kernel_events(None, None)
     lib.mm_diag_set_clock_buffer(None)
     kernel_us = e0.elapsed_time(e1) * 1e3
-    c = clk[:256].cpu().double()
+    c = clk.cpu().double()
+    c = c[c[:, 1] > 0][:256]     # the workgroups that ran (up to one round of them)
     cyc, ticks = c[:, 0], c[:, 1]
     ghz = (cyc / ticks * 0.1)
     start, end = c[:, 2], c[:, 2] + c[:, 3]
     print(f"   start spread {(start.max()-start.min())/100:.2f} us; loop end (rel. first start): median {(start+ticks-start.min()).median()/100:.1f} max {(start+ticks-start.min()).max()/100:.1f} us; "
           f"wave0 stores done: median {(end-start.min()).median()/100:.1f} max {(end-start.min()).max()/100:.1f} us; kernel (dispatch events) {kernel_us:.1f} us")
-    print(f"{tag:14s} {ROUNDING} split={split}: loop cycles median {cyc.median():.0f}  loop time median {ticks.median()*10/1000:.1f} us  clock median {ghz.median():.3f} GHz (min {ghz.min():.3f} max {ghz.max():.3f})", flush=True)
+    print(f"{tag:14s} {ROUNDING} M={M} split={split} ({len(c)} workgroups): loop cycles median {cyc.median():.0f}  loop time median {ticks.median()*10/1000:.1f} us  clock median {ghz.median():.3f} GHz (min {ghz.min():.3f} max {ghz.max():.3f})", flush=True)
