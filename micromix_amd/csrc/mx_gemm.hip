@@ -21,10 +21,13 @@
 //    directly: one dword per lane holds the 4 block scales of its row for a 128-K slab.
 //
 // Kernels by token count M:
-//  * M <= 64 : mx_gemm_skinny.hip -- weight-streaming, 32 features per workgroup, K split over the 8 waves
+//  * M <= 64 : mx_gemm_skinny.hip -- weight-streaming, 32 features per workgroup, K split over the 8 waves (for 32 < M <= 64 only
+//                                    while N / 32 workgroups fit one round and K is not split: mx_gemm_small_m_uses_tiles)
 //  * M  > 64 : mx_gemm256.hip     -- LDS-DMA pipelined 256x256 tiles when they fill the chip, else 128x256 / 128x128 tiles,
 //                                    64x128 / 64x64 tiles with loader and compute waves for the smallest launches, or split-K
 //                                    through a caller-provided workspace (plan_tiles / plan_splits, fitted to measurements)
+#include <stdlib.h>
+
 #include "mx_common.h"
 #include "mx_kernels.h"
 
@@ -32,7 +35,9 @@ namespace mm {
 
 hipError_t launch_mx_gemm(const GemmArgs &a, bool w4, hipStream_t stream) {
     if (a.M == 0 || a.N == 0) return hipSuccess;
-    if (a.M <= 64) return launch_mx_gemm_skinny(a, w4, stream);
+    static const int skinny_max = getenv("MICROMIX_SKINNY_MAX_M") ? atoi(getenv("MICROMIX_SKINNY_MAX_M")) : 64;   // kernel-developer override (<= 64)
+    if (a.M <= skinny_max && !mx_gemm_small_m_uses_tiles(a.M, a.N, a.K, a.ws ? a.ws_bytes : 0, a.force_split != 0))
+        return launch_mx_gemm_skinny(a, w4, stream);
     return launch_mx_gemm256(a, w4, stream);
 }
 

@@ -195,7 +195,7 @@ static int env_int(const char *name, int dflt) {
 // `force` (MM_SPLIT_K_ALWAYS, tests and tuning) skips the model.  MICROMIX_SPLITK=0 disables splitting, =S pins the split count.
 static int plan_splits(int M, int N, const int K[3], bool force, int first[4]) {
     static const int pinned = env_int("MICROMIX_SPLITK", -1);
-    if (pinned == 0 || M <= 64) return 0;
+    if (pinned == 0 || M <= 32) return 0;
     const int tiles = ((M + g128::BM - 1) / g128::BM) * ((N + g128::BN - 1) / g128::BN);
     int n[3], total = 0, nonempty = 0;
     for (int i = 0; i < 3; ++i) {
@@ -337,6 +337,18 @@ static TilePlan plan_tiles(int M, int N, const int K[3], bool have_ws, size_t ws
     }
     p.kind = use128 ? TK_G128 : TK_G256;
     return p;
+}
+
+// 32 < M <= 64: the weight-streaming kernel (two token tiles per workgroup, N / 32 workgroups) against the tiles.  Measured
+// (tools/mid_m_sweep.py 40 48 56 64): the skinny kernel costs ~10-13 us per ROUND of its workgroups at K = 4096, the 64-row tiles
+// 11-14 us flat, so the tiles win once N / 32 exceeds the CUs (gate/up, N = 14336: 22-25 -> 14 us); and a long K that the model
+// would split (down_proj, K = 14336: 25-30 us skinny) goes to the split-K tiles when the caller brought a workspace.
+bool mx_gemm_small_m_uses_tiles(int M, int N, const int K[3], size_t ws_bytes, bool force_split) {
+    if (M <= 32 || M > 64) return M > 64;
+    if ((N + 31) / 32 > device_cus()) return true;
+    if (ws_bytes == 0) return false;
+    const size_t need = mx_gemm_workspace_bytes(M, N, K, force_split);
+    return need > 0 && need <= ws_bytes;
 }
 
 const char *describe_mx_gemm256(int M, int N, const int K[3], bool w4, size_t ws_bytes, bool force_split) {

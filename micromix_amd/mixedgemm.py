@@ -212,7 +212,7 @@ def matmul(AN, BN, AS, BS, AO, BO, SFAN, SFBN, SFAS, SFBS, SFAO, SFBO, *, bias=N
     # shapes with few output tiles split K and need scratch for fp32 partial sums; it comes from torch's caching allocator
     # (stream-ordered, graph-capture safe) because the C ABI never allocates
     ws, ws_bytes = None, 0
-    if split_k and M > 64:
+    if split_k and M > 32:
         if split_k == "force":
             flags |= _lib.MM_SPLIT_K_ALWAYS
         ws_bytes = lib.mm_matmul_workspace_bytes(M, N, KN, KS, KO, wmode, flags)

@@ -81,7 +81,7 @@ class _DecodePlan:
             total += (sz + 255) & ~255
         ws_bytes = self.ws_bytes.get(m)
         if ws_bytes is None:
-            ws_bytes = self.ws_bytes[m] = self.lib.mm_matmul_workspace_bytes(m, self.n, kn, ks, ko, self.wmode, self.flags) if m > 64 else 0
+            ws_bytes = self.ws_bytes[m] = self.lib.mm_matmul_workspace_bytes(m, self.n, kn, ks, ko, self.wmode, self.flags) if m > 32 else 0
         if torch.cuda.current_device() != self.index:
             with torch.cuda.device(self.index):
                 return self.run_two_op(x2d, bias)

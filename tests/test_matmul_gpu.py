@@ -51,6 +51,7 @@ SPLIT_SHAPES = [
     (65, 256, 512, (0, 0, 512)), (130, 256, 4096, (2048, 1024, 1024)), (128, 1024, 4096, (0, 0, 4096)),
     (256, 512, 1792, (1024, 128, 640)), (200, 300, 2048, (128, 1792, 128)), (512, 2048, 1024, (512, 512, 0)),
     (96, 640, 5120, (4096, 512, 512)), (192, 256, 14336, (12288, 1024, 1024)), (129, 264, 768, (256, 256, 256)),
+    (48, 256, 14336, (12288, 1024, 1024)),     # 32 < M <= 64 with a long K: split-K tiles instead of the skinny kernel
 ]
 
 
@@ -216,13 +217,14 @@ def test_full_size_properties(dev):
 # one problem per tile kernel of mx_gemm256.hip (the dispatch is asserted, so a change of plan_tiles cannot silently drop one):
 # ragged M and N, all three segments, both weight modes; oracle on a row sample over every column
 TILE_KERNELS = [
-    ("g32n", "64x64", 250, 4000), ("g32", "64x128", 500, 4090), ("g64", "128x128", 700, 4090),
+    ("g32n", "64x64", 250, 4000), ("g32n", "64x64", 50, 8230),   # 32 < M <= 64 and more than a round of skinny workgroups: tiles
+    ("g32", "64x128", 500, 4090), ("g64", "128x128", 700, 4090),
     ("g128", "128x256", 1500, 4000), ("g256", "256x256", 4000, 4090),
 ]
 
 
 @pytest.mark.parametrize("wmode", ("w4", "w"))
-@pytest.mark.parametrize("ns,tile,M,N", TILE_KERNELS, ids=[t[0] for t in TILE_KERNELS])
+@pytest.mark.parametrize("ns,tile,M,N", TILE_KERNELS, ids=[f"{t[0]}-{t[2]}" for t in TILE_KERNELS])
 def test_every_tile_kernel(dev, ns, tile, M, N, wmode):
     import torch
     from micromix_amd import _lib
@@ -239,6 +241,7 @@ def test_every_tile_kernel(dev, ns, tile, M, N, wmode):
     for rounding in ("reference", "fused"):
         d = mixedgemm.matmul(a[0], b[0], a[1], b[1], a[2], b[2], a[3], b[3], a[4], b[4], a[5], b[5], rounding=rounding, split_k=False)
         rows = np.unique(np.concatenate([rng.choice(M, 24, replace=False), [0, 63, 64, 127, 128, M - 1]]))
+        rows = rows[rows < M]
         qx = o.reorder_quantize(xb[rows], idx, *split, "x")
         check_gemm(bits_from_t(d)[rows], qx, [u8(t) for t in b], rounding, label=f"{ns} {M}x{N} {wmode} {rounding}")
 
