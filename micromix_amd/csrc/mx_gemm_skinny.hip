@@ -81,25 +81,45 @@ __device__ __forceinline__ void run_segment(v16f (&acc)[TM], const uint8_t *X, c
     for (int t = 0; t < TM; ++t) sfx_off[t] = li * 16 + t * 4;  // rows t*32 + li < 128: atom row-tile 0
     const int sh = 8 * kb;
 
-    for (int s = wave; s < nslab; s += NW) {
-        const int sw = __builtin_amdgcn_raw_buffer_load_b32(rsw, sfw_off, s * 512, 0) >> sh;
-        int sx[TM];
+    // Two slabs in flight per wave: the loads of slab s + 8 are issued before the MFMAs of slab s wait for theirs (one slab at a
+    // time, a wave paid a full memory round trip per slab: four in a row at K = 4096).
+    struct Ops {
         v8i xf[TM][2], wf[2];
+        int sx[TM], sw;
+    };
+    auto load = [&](Ops &o, int s) {
+        o.sw = __builtin_amdgcn_raw_buffer_load_b32(rsw, sfw_off, s * 512, 0);
 #pragma unroll
-        for (int h = 0; h < 2; ++h) wf[h] = load_frag<WEL>(rw, li * wrb, s, h, kb);
-#pragma unroll
-        for (int t = 0; t < TM; ++t) {
-            sx[t] = __builtin_amdgcn_raw_buffer_load_b32(rsx, sfx_off[t], s * 512, 0) >> sh;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) xf[t][h] = load_frag<XEL>(rx, (t * 32 + li) * xrb, s, h, kb);
-        }
+        for (int h = 0; h < 2; ++h) o.wf[h] = load_frag<WEL>(rw, li * wrb, s, h, kb);
 #pragma unroll
         for (int t = 0; t < TM; ++t) {
-            acc[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(xf[t][0], wf[0], acc[t], ElemTraits<XEL>::HW,
-                                                                    ElemTraits<WEL>::HW, 0, sx[t], 0, sw);
-            acc[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(xf[t][1], wf[1], acc[t], ElemTraits<XEL>::HW,
-                                                                    ElemTraits<WEL>::HW, 2, sx[t], 2, sw);
+            o.sx[t] = __builtin_amdgcn_raw_buffer_load_b32(rsx, sfx_off[t], s * 512, 0);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) o.xf[t][h] = load_frag<XEL>(rx, (t * 32 + li) * xrb, s, h, kb);
         }
+    };
+    auto mfma = [&](const Ops &o) {
+        const int sw = o.sw >> sh;
+#pragma unroll
+        for (int t = 0; t < TM; ++t) {
+            const int sx = o.sx[t] >> sh;
+            acc[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(o.xf[t][0], o.wf[0], acc[t], ElemTraits<XEL>::HW,
+                                                                    ElemTraits<WEL>::HW, 0, sx, 0, sw);
+            acc[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(o.xf[t][1], o.wf[1], acc[t], ElemTraits<XEL>::HW,
+                                                                    ElemTraits<WEL>::HW, 2, sx, 2, sw);
+        }
+    };
+    Ops o0, o1;
+    int s = wave;
+    if (s < nslab) load(o0, s);
+    while (s < nslab) {
+        const int s1 = s + NW, s2 = s + 2 * NW;
+        if (s1 < nslab) load(o1, s1);
+        mfma(o0);
+        if (s1 >= nslab) break;
+        if (s2 < nslab) load(o0, s2);
+        mfma(o1);
+        s = s2;
     }
 }
 
@@ -288,7 +308,7 @@ __device__ __forceinline__ void skinny16_body(const GemmArgs &a) {
 }
 
 template <bool W4, int TM>
-__global__ void __launch_bounds__(NT) mx_gemm_skinny_kernel(GemmArgs a) { skinny_body<W4, TM>(a); }
+__global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(TM == 1 ? 4 : 2, TM == 1 ? 4 : 2))) mx_gemm_skinny_kernel(GemmArgs a) { skinny_body<W4, TM>(a); }
 template <bool W4, int T16>
 __global__ void __launch_bounds__(NT) mx_gemm_skinny16_kernel(GemmArgs a) { skinny16_body<W4, T16>(a); }
 
