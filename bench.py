@@ -326,6 +326,21 @@ def main():
             del am, bm
         result["mixed"] = mixed
 
+        # ---- launches with few tiles: the first M rows of the same activations against the q/o weights (64-row tiles) ----
+        few, fsplit = {}, (2048, 128, 1920)
+        bf = mixedgemm.reorder_quantize_w4(w, idx, *fsplit)
+        for m_ in (128, 256, 512):
+            af = mixedgemm.reorder_quantize_x(x[:m_].contiguous(), idx, *fsplit)
+            of = torch.empty((m_, N), dtype=torch.bfloat16, device=dev)
+            f = lambda: mm(af, bf, of)
+            settle(f, 0.2)
+            us = kernel_us(f, args.steps)
+            few[f"q_o_M{m_}"] = {"M": m_, "N": N, "K": K, "split": list(fsplit), "kernel_us": round(us, 2),
+                                 "tflops": round(2.0 * m_ * N * K / us / 1e6, 1),
+                                 "kernel": lib.mm_matmul_describe(m_, N, *fsplit, 1, 0, 0).decode()}
+        del bf
+        result["few_tiles"] = few
+
         # ---- the full QLinearLayer.forward hot path, and the "w" weight mode ----
         def timed(fn):
             for _ in range(args.warmup):
