@@ -246,6 +246,36 @@ def test_every_tile_kernel(dev, ns, tile, M, N, wmode):
         check_gemm(bits_from_t(d)[rows], qx, [u8(t) for t in b], rounding, label=f"{ns} {M}x{N} {wmode} {rounding}")
 
 
+def _boundary_shapes():
+    """token / feature counts on both sides of every dispatch threshold of mx_gemm.hip / plan_tiles (16 | 32 | 64 rows for the
+    skinny kernels, N / 32 against the CUs, the 64x64 / 64x128 / 128x128 / 128x256 tile rounds), with ragged edges"""
+    shapes = []
+    for m in (15, 16, 17, 31, 32, 33, 47, 48, 49, 63, 64, 65, 127, 129, 191, 193, 255, 257):
+        for n in (40, 264, 4104, 8200):
+            shapes.append((m, n))
+    shapes += [(256, 4096), (257, 4096), (512, 4096), (513, 4100), (385, 4096), (1025, 1000), (640, 2060)]
+    return shapes
+
+
+@pytest.mark.parametrize("m,n", _boundary_shapes(), ids=[f"{m}x{n}" for m, n in _boundary_shapes()])
+def test_dispatch_boundaries(dev, m, n):
+    """every kernel family at its edges: oracle on a row sample over every column, w4 weights, reference rounding, all three
+    segments; the 8 or fewer features past a multiple of 8 take the scalar store path"""
+    import torch
+    K, split = 384, (128, 128, 128)
+    rng = np.random.default_rng(m * 131 + n)
+    xb = make_inputs(rng, m, K)
+    wb = make_inputs(rng, n, K, "weight")
+    idx = rng.permutation(K).astype(np.int16)
+    x, w, tidx = t_from_bits(xb, dev), t_from_bits(wb, dev), torch.from_numpy(idx).to(dev)
+    a = mixedgemm.reorder_quantize_x(x, tidx, *split)
+    b = mixedgemm.reorder_quantize_w4(w, tidx, *split)
+    d = mixedgemm.matmul(a[0], b[0], a[1], b[1], a[2], b[2], a[3], b[3], a[4], b[4], a[5], b[5])
+    rows = np.unique(np.concatenate([rng.choice(m, min(m, 20), replace=False), [0, m - 1, min(m - 1, 63), min(m - 1, 64)]]))
+    qx = o.reorder_quantize(xb[rows], idx, *split, "x")
+    check_gemm(bits_from_t(d)[rows], qx, [u8(t) for t in b], "reference", label=f"boundary {m}x{n}")
+
+
 def test_tail_balanced_launch(dev):
     """more 256x256 tiles than CUs with a small remainder: the launcher runs the last tile columns as 128-row tiles (two
     launches).  M=2048, N=8448 -> 8 x 33 = 264 tiles = 256 + one column.  Oracle on a row sample, every column."""
