@@ -143,7 +143,7 @@ int mm_matmul(const uint8_t *AN, const uint8_t *BN, const uint8_t *AS, const uin
               const void *bias_bf16, void *D_bf16, mm_stream_t stream);
 
 /*
- * mm_matmul with a caller-owned scratch buffer.  For shapes with few output tiles (medium M or small N; M > 64) the GEMM
+ * mm_matmul with a caller-owned scratch buffer.  For shapes with few output tiles (medium M or small N; M > 32) the GEMM
  * splits K across workgroups, which needs room for fp32 partial sums; the library never allocates, so the caller passes
  *   workspace        device buffer of at least mm_matmul_workspace_bytes(...) bytes, 16-byte aligned, not shared with a
  *                    call that may run concurrently on another stream (NULL or too small: same results, without the split)
@@ -208,7 +208,7 @@ const char *mm_test_function(void);
  * Measurement hooks (used by bench.py and tools/gemm_clock.py; they change no result).  Both are THREAD-LOCAL: they affect
  * only launches made by the calling thread, so concurrent users of the library never see each other's hooks.
  *
- * mm_diag_set_kernel_events: while a pair of hipEvent_t is registered, every tiled-GEMM launch (M > 64) of this thread
+ * mm_diag_set_kernel_events: while a pair of hipEvent_t is registered, every tiled-GEMM launch (M > 64, and the M > 32 shapes that run on tiles) of this thread
  *   attaches them to its own dispatch (hipExtLaunchKernel start/stop events), so hipEventElapsedTime gives the kernel's
  *   duration as rocprofv3 reports it, without the launch gap that events recorded around the call include.  NULL, NULL disables.
  * mm_diag_set_clock_buffer: when a device buffer of 4 x 8 bytes per workgroup is registered, the large-M GEMM kernel stores
