@@ -279,7 +279,7 @@ struct TilePlan {
     int splits, split_first[4];
 };
 
-static TilePlan plan_tiles(int M, int N, const int K[3], bool have_ws, size_t ws_bytes, bool force_split) {
+static TilePlan plan_tiles(int M, int N, const int K[3], bool w4, bool have_ws, size_t ws_bytes, bool force_split) {
     TilePlan p{};
     p.tn = (N + 255) / 256;
     p.tm256 = (M + 255) / 256;
@@ -300,7 +300,11 @@ static TilePlan plan_tiles(int M, int N, const int K[3], bool have_ws, size_t ws
     static const int force = env_int("MICROMIX_GEMM_TILE", 0);   // kernel-developer override: 256, 128 or 64
     static const int tail_split = env_int("MICROMIX_GEMM_TAIL", 1);
     const int cus = device_cus();
-    if (force == 32 || force == 33) {
+    // The 64 x 128 tile exists for fp4 weights only: with matching-precision weights its loader slots and fragment sets need more
+    // than the 128 VGPRs of a 512-thread workgroup, hipcc then allocates temporaries in the AGPRs that hold the accumulators
+    // behind its back (they are asm clobbers, not live values, for it) and results are corrupted -- found by tools/stress.py,
+    // guarded against by tools/check_acc_regs.py (tests/test_build_guards.py).
+    if ((force == 32 && w4) || force == 33) {
         p.kind = force == 32 ? TK_G32 : TK_G32N;
         return p;
     }
@@ -311,7 +315,7 @@ static TilePlan plan_tiles(int M, int N, const int K[3], bool have_ws, size_t ws
         p.kind = TK_G32N;
         return p;
     }
-    if (force == 0 && p.tiles32 <= cus && 2 * p.tiles64 <= cus) {
+    if (force == 0 && w4 && p.tiles32 <= cus && 2 * p.tiles64 <= cus) {
         p.kind = TK_G32;
         return p;
     }
@@ -353,7 +357,7 @@ bool mx_gemm_small_m_uses_tiles(int M, int N, const int K[3], size_t ws_bytes, b
 
 const char *describe_mx_gemm256(int M, int N, const int K[3], bool w4, size_t ws_bytes, bool force_split) {
     static thread_local char buf[192];
-    const TilePlan p = plan_tiles(M, N, K, ws_bytes > 0, ws_bytes, force_split);
+    const TilePlan p = plan_tiles(M, N, K, w4, ws_bytes > 0, ws_bytes, force_split);
     const char *w = w4 ? "true" : "false";
     switch (p.kind) {
         case TK_SPLITK: snprintf(buf, sizeof(buf), "mm::g128::mx_gemm256_kernel<%s,true> x %d workgroups (128x256 tiles, split-K %d) + mm::splitk_reduce_kernel", w, p.tiles128 * p.splits, p.splits); break;
@@ -369,7 +373,7 @@ const char *describe_mx_gemm256(int M, int N, const int K[3], bool w4, size_t ws
 
 hipError_t launch_mx_gemm256(const GemmArgs &a, bool w4, hipStream_t stream) {
     static DynamicLdsOnce done[12];
-    const TilePlan p = plan_tiles(a.M, a.N, a.K, a.ws != nullptr, a.ws_bytes, a.force_split != 0);
+    const TilePlan p = plan_tiles(a.M, a.N, a.K, w4, a.ws != nullptr, a.ws_bytes, a.force_split != 0);
     switch (p.kind) {
         case TK_SPLITK: {
             GemmArgs b = a;
@@ -385,9 +389,8 @@ hipError_t launch_mx_gemm256(const GemmArgs &a, bool w4, hipStream_t stream) {
         case TK_G64:
             if (w4) return launch_tile(g64::mx_gemm256_kernel<true, false>, done[6], g64::Lds<true>::TOTAL, p.tiles64, g64::NT, a, stream);
             return launch_tile(g64::mx_gemm256_kernel<false, false>, done[7], g64::Lds<false>::TOTAL, p.tiles64, g64::NT, a, stream);
-        case TK_G32:
-            if (w4) return launch_tile(g32::mx_gemm256_kernel<true, false>, done[8], g32::Lds<true>::TOTAL, p.tiles32, g32::NTHREADS, a, stream);
-            return launch_tile(g32::mx_gemm256_kernel<false, false>, done[9], g32::Lds<false>::TOTAL, p.tiles32, g32::NTHREADS, a, stream);
+        case TK_G32:     // w4 only (plan_tiles)
+            return launch_tile(g32::mx_gemm256_kernel<true, false>, done[8], g32::Lds<true>::TOTAL, p.tiles32, g32::NTHREADS, a, stream);
         case TK_G32N:
             if (w4) return launch_tile(g32n::mx_gemm256_kernel<true, false>, done[10], g32n::Lds<true>::TOTAL, p.tiles32n, g32n::NTHREADS, a, stream);
             return launch_tile(g32n::mx_gemm256_kernel<false, false>, done[11], g32n::Lds<false>::TOTAL, p.tiles32n, g32n::NTHREADS, a, stream);
@@ -427,7 +430,7 @@ hipError_t launch_mx_gemm256_grouped(GroupedTileArgs &ga, bool w4, hipStream_t s
     const int t128 = tiles(128, 256), t64 = tiles(128, 128), t32 = tiles(64, 128), t32n = tiles(64, 64);
     int bm, bn;
     if (t32n <= cus) { bm = 64; bn = 64; }                         // the 4-wave tiles, as for a single problem (plan_tiles)
-    else if (t32 <= cus && 2 * t64 <= cus) { bm = 64; bn = 128; }
+    else if (w4 && t32 <= cus && 2 * t64 <= cus) { bm = 64; bn = 128; }   // fp4 weights only, see plan_tiles
     else if (2 * t128 <= cus && t64 <= cus) { bm = 128; bn = 128; }
     else if (t128 <= cus) { bm = 128; bn = 256; }
     else { bm = 256; bn = 256; }
@@ -444,8 +447,7 @@ hipError_t launch_mx_gemm256_grouped(GroupedTileArgs &ga, bool w4, hipStream_t s
     };
     if (bm == 64 && bn == 64) return w4 ? go(g32n::mx_gemm256_grouped_kernel<true>, done[6], g32n::Lds<true>::TOTAL, g32n::NTHREADS)
                                         : go(g32n::mx_gemm256_grouped_kernel<false>, done[7], g32n::Lds<false>::TOTAL, g32n::NTHREADS);
-    if (bm == 64) return w4 ? go(g32::mx_gemm256_grouped_kernel<true>, done[8], g32::Lds<true>::TOTAL, g32::NTHREADS)
-                            : go(g32::mx_gemm256_grouped_kernel<false>, done[9], g32::Lds<false>::TOTAL, g32::NTHREADS);
+    if (bm == 64) return go(g32::mx_gemm256_grouped_kernel<true>, done[8], g32::Lds<true>::TOTAL, g32::NTHREADS);
     if (bm == 256) return w4 ? go(g256::mx_gemm256_grouped_kernel<true>, done[0], g256::Lds<true>::TOTAL, g256::NT)
                              : go(g256::mx_gemm256_grouped_kernel<false>, done[1], g256::Lds<false>::TOTAL, g256::NT);
     if (bn == 256) return w4 ? go(g128::mx_gemm256_grouped_kernel<true>, done[2], g128::Lds<true>::TOTAL, g128::NT)

@@ -1,0 +1,41 @@
+"""Build-time guards (no GPU): properties of the generated code that the kernels rely on and that no numerical test would pin
+down deterministically."""
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc")
+def test_compiler_leaves_the_accumulator_agprs_alone():
+    """the tile kernels keep their accumulators in AGPRs that only inline asm touches; hipcc must not allocate temporaries there
+    (it did once, in a kernel that needed more than its VGPR budget: tools/check_acc_regs.py has the story)"""
+    import check_acc_regs
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, "k.s")
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-fno-gpu-rdc", "-S",
+                        "--cuda-device-only", os.path.join(ROOT, "micromix_amd", "csrc", "mx_gemm256.hip"), "-o", out],
+                       check=True, cwd=tmp, stderr=subprocess.DEVNULL)
+        text = open(out).read()
+    assert text.count(".end_amdhsa_kernel") >= 10            # the parser below must have kernels to look at
+    bad = check_acc_regs.check(text)
+    assert not bad, "\n".join(f"{s}: {c}" for s, c in bad[:10])
+
+
+def test_the_guard_itself_detects_a_violation():
+    import check_acc_regs
+    fake = ("_ZN2mm3g3217mx_gemm256_kernelILb0ELb0EEEvNS_8GemmArgsE: ; @x\n"
+            "\tv_mfma_scale_f32_32x32x64_f8f6f4 a[0:15], v[0:7], v[8:11], a[0:15], v3, v4 op_sel_hi:[0,0,0] cbsz:0 blgp:4\n"
+            "\tv_accvgpr_read_b32 v1, a[3]\n"
+            "\tds_read2st64_b64 a[0:3], v113 offset0:16 offset1:24\n"
+            "\tv_accvgpr_write_b32 a40, v2\n"
+            "\tv_accvgpr_read_b32 v5, a7\n"
+            ".end_amdhsa_kernel\n")
+    bad = check_acc_regs.check(fake)
+    assert [c.split()[0] for _, c in bad] == ["ds_read2st64_b64", "v_accvgpr_read_b32"]

@@ -230,7 +230,10 @@ def test_every_tile_kernel(dev, ns, tile, M, N, wmode):
     from micromix_amd import _lib
     K, split = 640, (256, 128, 256)
     desc = _lib.load().mm_matmul_describe(M, N, *split, 1 if wmode == "w4" else 0, 0, 0).decode()
-    assert f"mm::{ns}::" in desc and f"({tile} tiles" in desc, desc
+    if ns == "g32" and wmode == "w":
+        assert "mm::g64::" in desc, desc          # the 64 x 128 tile exists for fp4 weights only (plan_tiles)
+    else:
+        assert f"mm::{ns}::" in desc and f"({tile} tiles" in desc, desc
     rng = np.random.default_rng(M + N)
     xb = make_inputs(rng, M, K)
     wb = make_inputs(rng, N, K, "weight")
@@ -274,6 +277,32 @@ def test_dispatch_boundaries(dev, m, n):
     rows = np.unique(np.concatenate([rng.choice(m, min(m, 20), replace=False), [0, m - 1, min(m - 1, 63), min(m - 1, 64)]]))
     qx = o.reorder_quantize(xb[rows], idx, *split, "x")
     check_gemm(bits_from_t(d)[rows], qx, [u8(t) for t in b], "reference", label=f"boundary {m}x{n}")
+
+
+STRESS_REGRESSIONS = [   # found by tools/stress.py: many fp6 slabs at a token count that runs on few tiles, both weight modes
+    (300, 4096, (0, 1792, 0)), (300, 4128, (1280, 2176, 640)), (300, 4096, (2176, 1792, 128)), (500, 4090, (0, 2048, 2048)),
+]
+
+
+@pytest.mark.parametrize("wmode", ("w4", "w"))
+@pytest.mark.parametrize("m,n,split", STRESS_REGRESSIONS, ids=[f"{c[0]}x{c[1]}-{'_'.join(map(str, c[2]))}" for c in STRESS_REGRESSIONS])
+def test_many_slabs_on_few_tiles(dev, m, n, split, wmode):
+    import torch
+    K = sum(split)
+    rng = np.random.default_rng(m + n + K)
+    xb = make_inputs(rng, m, K)
+    wb = make_inputs(rng, n, K, "weight")
+    idx = rng.permutation(K).astype(np.int16)
+    x, w, tidx = t_from_bits(xb, dev), t_from_bits(wb, dev), torch.from_numpy(idx).to(dev)
+    a = mixedgemm.reorder_quantize_x(x, tidx, *split)
+    b = (mixedgemm.reorder_quantize_w4 if wmode == "w4" else mixedgemm.reorder_quantize_w)(w, tidx, *split)
+    args = (a[0], b[0], a[1], b[1], a[2], b[2], a[3], b[3], a[4], b[4], a[5], b[5])
+    d = mixedgemm.matmul(*args, split_k=False)
+    for _ in range(5):
+        assert torch.equal(mixedgemm.matmul(*args, split_k=False), d)          # run-to-run determinism
+    rows = np.unique(np.concatenate([rng.choice(m, 24, replace=False), [0, 63, 64, m - 1]]))
+    qx = o.reorder_quantize(xb[rows], idx, *split, "x")
+    check_gemm(bits_from_t(d)[rows], qx, [u8(t) for t in b], "reference", label=f"{m}x{n} {split} {wmode}")
 
 
 def test_tail_balanced_launch(dev):
