@@ -16,9 +16,10 @@ def rand_split(k):
     a = int(rng.integers(0, g + 1)); b = int(rng.integers(0, g - a + 1))
     return (a * 128, b * 128, (g - a - b) * 128)
 while time.time() < t_end:
-    m = int(rng.choice([1, 2, 5, 8, 9, 16, 17, 33, 48, 64, 65, 100, 128, 129, 200, 256, 300, 512, 700, 1024]))
-    n = int(rng.choice([16, 100, 128, 200, 256, 512, 1000, 1024, 2048, 4096, 4128]))
+    m = int(rng.choice([1, 2, 5, 8, 9, 16, 17, 33, 40, 48, 56, 64, 65, 100, 128, 129, 200, 256, 300, 384, 512, 700, 768, 1024, 1536, 2048, 4100]))
+    n = int(rng.choice([16, 100, 128, 200, 256, 512, 1000, 1024, 2048, 4096, 4128, 8200, 14336]))
     k = int(rng.choice([128, 256, 384, 512, 1024, 2048, 4096]))
+    if m * n > (1 << 23): k = min(k, 1024)      # keep the big outputs cheap
     split = rand_split(k)
     w4 = bool(rng.integers(0, 2)); rounding = "reference" if rng.integers(0, 2) else "fused"
     g = torch.Generator().manual_seed(int(rng.integers(0, 1 << 30)))
