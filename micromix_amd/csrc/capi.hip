@@ -132,16 +132,15 @@ int mm_qlinear_decode(const void *X_bf16, const int16_t *reorder_index, const ui
 }
 
 size_t mm_matmul_workspace_bytes(int M, int N, int KN, int KS, int KO, int wmode, int flags) {
-    (void)wmode;
     if (M <= 0 || N <= 0 || KN < 0 || KS < 0 || KO < 0 || (KN % 128) || (KS % 128) || (KO % 128)) return 0;
     const int K[3] = {KN, KS, KO};
-    return mm::mx_gemm_workspace_bytes(M, N, K, (flags & MM_SPLIT_K_ALWAYS) != 0);
+    return mm::mx_gemm_workspace_bytes(M, N, K, wmode == MM_W_FP4, (flags & MM_SPLIT_K_ALWAYS) != 0);
 }
 
 const char *mm_matmul_describe(int M, int N, int KN, int KS, int KO, int wmode, int flags, size_t workspace_bytes) {
     if (M <= 0 || N <= 0 || KN < 0 || KS < 0 || KO < 0 || (KN % 128) || (KS % 128) || (KO % 128) || KN + KS + KO == 0) return "none";
     const int K[3] = {KN, KS, KO};
-    if (M <= 64 && !mm::mx_gemm_small_m_uses_tiles(M, N, K, workspace_bytes, (flags & MM_SPLIT_K_ALWAYS) != 0))
+    if (M <= 64 && !mm::mx_gemm_small_m_uses_tiles(M, N, K, wmode == MM_W_FP4, workspace_bytes, (flags & MM_SPLIT_K_ALWAYS) != 0))
         return "mm::skinny::mx_gemm_skinny*_kernel (weight streaming, M <= 64)";
     return mm::describe_mx_gemm256(M, N, K, wmode == MM_W_FP4, workspace_bytes, (flags & MM_SPLIT_K_ALWAYS) != 0);
 }

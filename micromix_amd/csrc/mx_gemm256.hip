@@ -193,7 +193,7 @@ static int env_int(const char *name, int dflt) {
 //     t(S) = 0.7 * slabs / S + 0.064 * tiles * S (+ 5)   ->   S* = 3.3 * sqrt(slabs / tiles)
 // Split only when that beats the unsplit launch (the tile plan_tiles would pick at these tile counts, see below) by a margin.
 // `force` (MM_SPLIT_K_ALWAYS, tests and tuning) skips the model.  MICROMIX_SPLITK=0 disables splitting, =S pins the split count.
-static int plan_splits(int M, int N, const int K[3], bool force, int first[4]) {
+static int plan_splits(int M, int N, const int K[3], bool w4, bool force, int first[4]) {
     static const int pinned = env_int("MICROMIX_SPLITK", -1);
     if (pinned == 0 || M <= 32) return 0;
     const int tiles = ((M + g128::BM - 1) / g128::BM) * ((N + g128::BN - 1) / g128::BN);
@@ -219,7 +219,7 @@ static int plan_splits(int M, int N, const int K[3], bool force, int first[4]) {
         // split at M <= 384, unsplit 64 x 128 tiles at M = 512; k/v and q/o at K = 4096: never split).
         const int t32n = ((M + 63) / 64) * ((N + 63) / 64), t32 = ((M + 63) / 64) * ((N + 127) / 128);
         const int t64 = ((M + 127) / 128) * ((N + 127) / 128);
-        const bool g32n_fits = t32n <= 256, g32_fits = !g32n_fits && t32 <= 256 && 2 * t64 <= 256;
+        const bool g32n_fits = t32n <= 256, g32_fits = w4 && !g32n_fits && t32 <= 256 && 2 * t64 <= 256;   // as plan_tiles
         const float unsplit = (g32n_fits ? 0.32f : g32_fits ? 0.36f : 0.5f) * total, margin = g32_fits ? 0.95f : 0.85f;
         const float split = 0.7f * total / S + 0.064f * tiles * S + 5.0f;
         if (S < 2 || split > margin * unsplit) return 0;
@@ -252,9 +252,9 @@ static int plan_splits(int M, int N, const int K[3], bool force, int first[4]) {
     return first[3];
 }
 
-size_t mx_gemm_workspace_bytes(int M, int N, const int K[3], bool force) {
+size_t mx_gemm_workspace_bytes(int M, int N, const int K[3], bool w4, bool force) {
     int first[4];
-    const int S = plan_splits(M, N, K, force, first);
+    const int S = plan_splits(M, N, K, w4, force, first);
     if (S == 0) return 0;
     const size_t tiles = (size_t)((M + g128::BM - 1) / g128::BM) * ((N + g128::BN - 1) / g128::BN);
     return tiles * S * SPLIT_WG_FLOATS * sizeof(float);
@@ -290,7 +290,7 @@ static TilePlan plan_tiles(int M, int N, const int K[3], bool w4, bool have_ws, 
     p.tiles32 = ((M + 63) / 64) * ((N + 127) / 128);
     p.tiles32n = ((M + 63) / 64) * ((N + 63) / 64);
     if (have_ws) {
-        p.splits = plan_splits(M, N, K, force_split, p.split_first);
+        p.splits = plan_splits(M, N, K, w4, force_split, p.split_first);
         if (p.splits && (size_t)p.tiles128 * p.splits * SPLIT_WG_FLOATS * sizeof(float) <= ws_bytes) {
             p.kind = TK_SPLITK;
             return p;
@@ -347,11 +347,11 @@ static TilePlan plan_tiles(int M, int N, const int K[3], bool w4, bool have_ws, 
 // (tools/mid_m_sweep.py 40 48 56 64): the skinny kernel costs ~10-13 us per ROUND of its workgroups at K = 4096, the 64-row tiles
 // 11-14 us flat, so the tiles win once N / 32 exceeds the CUs (gate/up, N = 14336: 22-25 -> 14 us); and a long K that the model
 // would split (down_proj, K = 14336: 25-30 us skinny) goes to the split-K tiles when the caller brought a workspace.
-bool mx_gemm_small_m_uses_tiles(int M, int N, const int K[3], size_t ws_bytes, bool force_split) {
+bool mx_gemm_small_m_uses_tiles(int M, int N, const int K[3], bool w4, size_t ws_bytes, bool force_split) {
     if (M <= 32 || M > 64) return M > 64;
     if ((N + 31) / 32 > device_cus()) return true;
     if (ws_bytes == 0) return false;
-    const size_t need = mx_gemm_workspace_bytes(M, N, K, force_split);
+    const size_t need = mx_gemm_workspace_bytes(M, N, K, w4, force_split);
     return need > 0 && need <= ws_bytes;
 }
 

@@ -101,8 +101,8 @@ hipError_t launch_mx_gemm(const GemmArgs &a, bool w4, hipStream_t stream);
 hipError_t launch_mx_gemm256(const GemmArgs &a, bool w4, hipStream_t stream);
 hipError_t launch_mx_gemm_skinny(const GemmArgs &a, bool w4, hipStream_t stream);
 hipError_t launch_mx_gemm_skinny_grouped(const GroupedGemmArgs &ga, int max_m, bool w4, hipStream_t stream);
-size_t mx_gemm_workspace_bytes(int M, int N, const int K[3], bool force);
-bool mx_gemm_small_m_uses_tiles(int M, int N, const int K[3], size_t ws_bytes, bool force_split);
+size_t mx_gemm_workspace_bytes(int M, int N, const int K[3], bool w4, bool force);
+bool mx_gemm_small_m_uses_tiles(int M, int N, const int K[3], bool w4, size_t ws_bytes, bool force_split);
 const char *describe_mx_gemm256(int M, int N, const int K[3], bool w4, size_t ws_bytes, bool force_split);   // thread-local buffer  // 0 when mm_matmul would not split K for this shape
 
 }  // namespace mm
