@@ -219,7 +219,7 @@ static int plan_splits(int M, int N, const int K[3], bool w4, bool force, int fi
         // split at M <= 384, unsplit 64 x 128 tiles at M = 512; k/v and q/o at K = 4096: never split).
         const int t32n = ((M + 63) / 64) * ((N + 63) / 64), t32 = ((M + 63) / 64) * ((N + 127) / 128);
         const int t64 = ((M + 127) / 128) * ((N + 127) / 128);
-        const bool g32n_fits = t32n <= 256, g32_fits = w4 && !g32n_fits && t32 <= 256 && 2 * t64 <= 256;   // as plan_tiles
+        const bool g32n_fits = t32n <= 256, g32_fits = !g32n_fits && t32 <= 256 && 2 * t64 <= 256;   // as plan_tiles
         const float unsplit = (g32n_fits ? 0.32f : g32_fits ? 0.36f : 0.5f) * total, margin = g32_fits ? 0.95f : 0.85f;
         const float split = 0.7f * total / S + 0.064f * tiles * S + 5.0f;
         if (S < 2 || split > margin * unsplit) return 0;
@@ -300,11 +300,7 @@ static TilePlan plan_tiles(int M, int N, const int K[3], bool w4, bool have_ws, 
     static const int force = env_int("MICROMIX_GEMM_TILE", 0);   // kernel-developer override: 256, 128 or 64
     static const int tail_split = env_int("MICROMIX_GEMM_TAIL", 1);
     const int cus = device_cus();
-    // The 64 x 128 tile exists for fp4 weights only: with matching-precision weights its loader slots and fragment sets need more
-    // than the 128 VGPRs of a 512-thread workgroup, hipcc then allocates temporaries in the AGPRs that hold the accumulators
-    // behind its back (they are asm clobbers, not live values, for it) and results are corrupted -- found by tools/stress.py,
-    // guarded against by tools/check_acc_regs.py (tests/test_build_guards.py).
-    if ((force == 32 && w4) || force == 33) {
+    if (force == 32 || force == 33) {
         p.kind = force == 32 ? TK_G32 : TK_G32N;
         return p;
     }
@@ -315,7 +311,7 @@ static TilePlan plan_tiles(int M, int N, const int K[3], bool w4, bool have_ws, 
         p.kind = TK_G32N;
         return p;
     }
-    if (force == 0 && w4 && p.tiles32 <= cus && 2 * p.tiles64 <= cus) {
+    if (force == 0 && p.tiles32 <= cus && 2 * p.tiles64 <= cus) {
         p.kind = TK_G32;
         return p;
     }
@@ -389,8 +385,9 @@ hipError_t launch_mx_gemm256(const GemmArgs &a, bool w4, hipStream_t stream) {
         case TK_G64:
             if (w4) return launch_tile(g64::mx_gemm256_kernel<true, false>, done[6], g64::Lds<true>::TOTAL, p.tiles64, g64::NT, a, stream);
             return launch_tile(g64::mx_gemm256_kernel<false, false>, done[7], g64::Lds<false>::TOTAL, p.tiles64, g64::NT, a, stream);
-        case TK_G32:     // w4 only (plan_tiles)
-            return launch_tile(g32::mx_gemm256_kernel<true, false>, done[8], g32::Lds<true>::TOTAL, p.tiles32, g32::NTHREADS, a, stream);
+        case TK_G32:
+            if (w4) return launch_tile(g32::mx_gemm256_kernel<true, false>, done[8], g32::Lds<true>::TOTAL, p.tiles32, g32::NTHREADS, a, stream);
+            return launch_tile(g32::mx_gemm256_kernel<false, false>, done[9], g32::Lds<false>::TOTAL, p.tiles32, g32::NTHREADS, a, stream);
         case TK_G32N:
             if (w4) return launch_tile(g32n::mx_gemm256_kernel<true, false>, done[10], g32n::Lds<true>::TOTAL, p.tiles32n, g32n::NTHREADS, a, stream);
             return launch_tile(g32n::mx_gemm256_kernel<false, false>, done[11], g32n::Lds<false>::TOTAL, p.tiles32n, g32n::NTHREADS, a, stream);
@@ -430,7 +427,7 @@ hipError_t launch_mx_gemm256_grouped(GroupedTileArgs &ga, bool w4, hipStream_t s
     const int t128 = tiles(128, 256), t64 = tiles(128, 128), t32 = tiles(64, 128), t32n = tiles(64, 64);
     int bm, bn;
     if (t32n <= cus) { bm = 64; bn = 64; }                         // the 4-wave tiles, as for a single problem (plan_tiles)
-    else if (w4 && t32 <= cus && 2 * t64 <= cus) { bm = 64; bn = 128; }   // fp4 weights only, see plan_tiles
+    else if (t32 <= cus && 2 * t64 <= cus) { bm = 64; bn = 128; }
     else if (2 * t128 <= cus && t64 <= cus) { bm = 128; bn = 128; }
     else if (t128 <= cus) { bm = 128; bn = 256; }
     else { bm = 256; bn = 256; }
@@ -447,7 +444,8 @@ hipError_t launch_mx_gemm256_grouped(GroupedTileArgs &ga, bool w4, hipStream_t s
     };
     if (bm == 64 && bn == 64) return w4 ? go(g32n::mx_gemm256_grouped_kernel<true>, done[6], g32n::Lds<true>::TOTAL, g32n::NTHREADS)
                                         : go(g32n::mx_gemm256_grouped_kernel<false>, done[7], g32n::Lds<false>::TOTAL, g32n::NTHREADS);
-    if (bm == 64) return go(g32::mx_gemm256_grouped_kernel<true>, done[8], g32::Lds<true>::TOTAL, g32::NTHREADS);
+    if (bm == 64) return w4 ? go(g32::mx_gemm256_grouped_kernel<true>, done[8], g32::Lds<true>::TOTAL, g32::NTHREADS)
+                            : go(g32::mx_gemm256_grouped_kernel<false>, done[9], g32::Lds<false>::TOTAL, g32::NTHREADS);
     if (bm == 256) return w4 ? go(g256::mx_gemm256_grouped_kernel<true>, done[0], g256::Lds<true>::TOTAL, g256::NT)
                              : go(g256::mx_gemm256_grouped_kernel<false>, done[1], g256::Lds<false>::TOTAL, g256::NT);
     if (bn == 256) return w4 ? go(g128::mx_gemm256_grouped_kernel<true>, done[2], g128::Lds<true>::TOTAL, g128::NT)

@@ -230,10 +230,7 @@ def test_every_tile_kernel(dev, ns, tile, M, N, wmode):
     from micromix_amd import _lib
     K, split = 640, (256, 128, 256)
     desc = _lib.load().mm_matmul_describe(M, N, *split, 1 if wmode == "w4" else 0, 0, 0).decode()
-    if ns == "g32" and wmode == "w":
-        assert "mm::g64::" in desc, desc          # the 64 x 128 tile exists for fp4 weights only (plan_tiles)
-    else:
-        assert f"mm::{ns}::" in desc and f"({tile} tiles" in desc, desc
+    assert f"mm::{ns}::" in desc and f"({tile} tiles" in desc, desc
     rng = np.random.default_rng(M + N)
     xb = make_inputs(rng, M, K)
     wb = make_inputs(rng, N, K, "weight")
