@@ -30,7 +30,7 @@ def test_compiler_leaves_the_accumulator_agprs_alone():
 
 def test_the_guard_itself_detects_a_violation():
     import check_acc_regs
-    fake = ("_ZN2mm3g3217mx_gemm256_kernelILb0ELb0EEEvNS_8GemmArgsE: ; @x\n"
+    fake = ("_ZN2mm3g6417mx_gemm256_kernelILb0ELb0EEEvNS_8GemmArgsE: ; @x\n"
             "\tv_mfma_scale_f32_32x32x64_f8f6f4 a[0:15], v[0:7], v[8:11], a[0:15], v3, v4 op_sel_hi:[0,0,0] cbsz:0 blgp:4\n"
             "\tv_accvgpr_read_b32 v1, a[3]\n"
             "\tds_read2st64_b64 a[0:3], v113 offset0:16 offset1:24\n"
