@@ -180,7 +180,7 @@ def main():
             torch.cuda.synchronize()
         return time.perf_counter() - t0
 
-    def kernel_us(fn, steps):
+    def kernel_us(fn, steps, stat=np.mean):
         """mean duration of the tiled-GEMM dispatch inside fn(): HIP events attached to the dispatch itself (hipExtLaunchKernel
         start/stop events, mm_diag_set_kernel_events) on the stream the kernel runs on -- they bracket exactly what rocprofv3's
         kernel trace reports.  (Events recorded AROUND the call would include the ~4 us launch gap in every sample.)"""
@@ -194,7 +194,7 @@ def main():
             fn()
         lib.mm_diag_set_kernel_events(None, None)
         torch.cuda.synchronize()
-        return float(np.mean([e0.elapsed_time(e1) for e0, e1 in evs])) * 1e3
+        return float(stat([e0.elapsed_time(e1) for e0, e1 in evs])) * 1e3
 
     extra = {}
     if world == 1:
@@ -333,9 +333,9 @@ def main():
             af = mixedgemm.reorder_quantize_x(x[:m_].contiguous(), idx, *fsplit)
             of = torch.empty((m_, N), dtype=torch.bfloat16, device=dev)
             f = lambda: mm(af, bf, of)
-            settle(f, 0.2)
-            us = kernel_us(f, args.steps)
-            few[f"q_o_M{m_}"] = {"M": m_, "N": N, "K": K, "split": list(fsplit), "kernel_us": round(us, 2),
+            settle(f, 0.3)
+            us = kernel_us(f, args.steps, np.median)     # 12 us kernels: one late dispatch would move a mean by 10 %
+            few[f"q_o_M{m_}"] = {"M": m_, "N": N, "K": K, "split": list(fsplit), "kernel_us": round(us, 2), "kernel_us_stat": "median",
                                  "tflops": round(2.0 * m_ * N * K / us / 1e6, 1),
                                  "kernel": lib.mm_matmul_describe(m_, N, *fsplit, 1, 0, 0).decode()}
         del bf
