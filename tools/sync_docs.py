@@ -43,4 +43,31 @@ t = open(p).read()
 t = re.sub(r"fp8×fp4 [\d.]+ µs = [\d.]+ PFLOP/s = [\d.]+ of the fp8 peak on the profiled box", f"fp8×fp4 {k:.1f} µs = {pf(k):.2f} PFLOP/s = {frac:.3f} of the fp8 peak on the profiled box", t)
 t = re.sub(r"\(2048,128,1920\) [\d.]+ µs; all-fp4 [\d.]+ µs = [\d.]+ PFLOP/s;", f"(2048,128,1920) {a['kernel_us']:.1f} µs; all-fp4 {c['kernel_us']:.1f} µs = {pf(c['kernel_us']):.2f} PFLOP/s;", t)
 open(p, "w").write(t)
+# --- the shape table of DESIGN.md section 4.4 from profiles/r02_llama_shapes.txt
+rows = {}
+for l in open(os.path.join(ROOT, "profiles", "r02_llama_shapes.txt")):
+    m = re.match(r"(\S+)\s+(\d+)\s+(\d+)\s+(\d+)\s+(\(.*?\))\s+\|\s+([\d.]+)\s+(\d+)\s+\|\s+([\d.]+)", l)
+    if m:
+        name, N, K, M, split, g, tf, q = m.groups()
+        rows[(name, split.replace(" ", ""), int(M))] = (float(g), int(tf), float(q))
+Ms = [1, 16, 128, 256, 512, 2048, 4096]
+def gline(label, name, split):
+    return f"| {label} | " + " | ".join(f"{rows[(name, split, M)][0]:.1f}" + (f" ({rows[(name, split, M)][1] / 1000:.2f} PF)" if M >= 2048 else "") for M in Ms) + " |"
+def qline(label, split):
+    return f"| {label} | " + " | ".join(f"{rows[('q/o_proj', split, M)][2]:.1f}" for M in Ms) + " |"
+table = ["| layer (N×K), split | M=1 | 16 | 128 | 256 | 512 | 2048 | 4096 |", "|---|---|---|---|---|---|---|---|",
+         gline("q/o 4096×4096 (0,0,4096)", "q/o_proj", "(0,0,4096)"), gline("q/o (2048,128,1920)", "q/o_proj", "(2048,128,1920)"),
+         gline("q/o (3072,896,128)", "q/o_proj", "(3072,896,128)"), gline("k/v 1024×4096 (0,0,4096)", "k/v_proj", "(0,0,4096)"),
+         gline("gate/up 14336×4096 (0,0,4096)", "gate/up_proj", "(0,0,4096)"), gline("gate/up (3072,896,128)", "gate/up_proj", "(3072,896,128)"),
+         gline("down 4096×14336 (7168,512,6656)", "down_proj", "(7168,512,6656)"), gline("down (12288,1024,1024)", "down_proj", "(12288,1024,1024)"),
+         qline("quantize-x, K=4096 (0,0,4096)", "(0,0,4096)"), qline("quantize-x, K=4096 (3072,896,128)", "(3072,896,128)")]
+s2 = open(design).read()
+i0 = s2.index("| layer (N×K), split | M=1 | 16 | 128 | 256 | 512 | 2048 | 4096 |")
+i1 = s2.index("(full table: `profiles/r02_llama_shapes.txt`")
+s2 = s2[:i0] + "\n".join(table) + "\n\n" + s2[i1:]
+g_ = lambda n, sp: rows[(n, sp, 4096)][0]
+s2 = re.sub(r"down \(12288,1024,1024\) at M=4096 133\.3 → [\d.]+ µs, gate/up \(3072,896,128\) 196\.7 → [\d.]+ µs, q/o \(3072,896,128\) 55\.7 → [\d.]+ µs",
+            f"down (12288,1024,1024) at M=4096 133.3 → {g_('down_proj', '(12288,1024,1024)')} µs, gate/up (3072,896,128) 196.7 → {g_('gate/up_proj', '(3072,896,128)')} µs, "
+            f"q/o (3072,896,128) 55.7 → {g_('q/o_proj', '(3072,896,128)')} µs", s2)
+open(design, "w").write(s2)
 print(f"headline {k} us frac {frac} value {val}; trace event pass {ev}; few_tiles", {n: v["kernel_us"] for n, v in d.get("few_tiles", {}).items()})
