@@ -9,6 +9,9 @@
 // the pair costs two floors.  Here every workgroup (32 output features, 8 waves) first quantizes the M activation rows into
 // LDS by itself -- the rows are a few KB, re-reading them from L2 in every workgroup is free compared with a second launch --
 // and then runs the skinny GEMM with the activation fragments and scales coming from LDS and only the weights from HBM.
+#ifndef MM_DECODE_DEPTH
+#define MM_DECODE_DEPTH 4   // weight slabs a wave requests at once (1 = one memory round trip per slab)
+#endif
 #include "mx_group_convert.h"
 #include "mx_kernels.h"
 
@@ -105,21 +108,39 @@ __device__ __forceinline__ void run_segment(v16f &acc, const uint8_t *xl, int xp
     const uint8_t *xrow = xl + (valid ? li : 0) * xp;
     const uint8_t *srow = sl + (valid ? li : 0) * sp;
     const int sh = 8 * kb;
-    for (int s = wave; s < nslab; s += NW) {
-        const int sw = __builtin_amdgcn_raw_buffer_load_b32(rsw, sfw_off, s * 512, 0) >> sh;
-        v8i wf[2], xf[2];
+    // The weights are the only global loads of this loop and depend on nothing: a wave requests DEPTH of its slabs at once
+    // (wave-uniform tests for the tail) and then walks them, instead of paying one memory round trip per slab.
+    constexpr int DEPTH = MM_DECODE_DEPTH;
+    for (int s0 = wave; s0 < nslab; s0 += DEPTH * NW) {
+        v8i wf[DEPTH][2];
+        int swr[DEPTH];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) wf[h] = load_wfrag<WEL>(rw, li * wrb, s, h, kb);
-        int sx = 0;
-        const v8i zero = {0, 0, 0, 0, 0, 0, 0, 0};
-        xf[0] = xf[1] = zero;
-        if (valid) {
-            sx = (int)(*reinterpret_cast<const uint32_t *>(srow + 4 * s) >> sh);
+        for (int j = 0; j < DEPTH; ++j) {
+            const int s = s0 + j * NW;
+            if (s < nslab) {
+                swr[j] = __builtin_amdgcn_raw_buffer_load_b32(rsw, sfw_off, s * 512, 0);
 #pragma unroll
-            for (int h = 0; h < 2; ++h) xf[h] = lds_xfrag<XEL>(xrow + s * G<XEL>::BYTES, h, kb);
+                for (int h = 0; h < 2; ++h) wf[j][h] = load_wfrag<WEL>(rw, li * wrb, s, h, kb);
+            }
         }
-        acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(xf[0], wf[0], acc, ElemTraits<XEL>::HW, ElemTraits<WEL>::HW, 0, sx, 0, sw);
-        acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(xf[1], wf[1], acc, ElemTraits<XEL>::HW, ElemTraits<WEL>::HW, 2, sx, 2, sw);
+#pragma unroll
+        for (int j = 0; j < DEPTH; ++j) {
+            const int s = s0 + j * NW;
+            if (s < nslab) {
+                const int sw = swr[j] >> sh;
+                v8i xf[2];
+                int sx = 0;
+                const v8i zero = {0, 0, 0, 0, 0, 0, 0, 0};
+                xf[0] = xf[1] = zero;
+                if (valid) {
+                    sx = (int)(*reinterpret_cast<const uint32_t *>(srow + 4 * s) >> sh);
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) xf[h] = lds_xfrag<XEL>(xrow + s * G<XEL>::BYTES, h, kb);
+                }
+                acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(xf[0], wf[j][0], acc, ElemTraits<XEL>::HW, ElemTraits<WEL>::HW, 0, sx, 0, sw);
+                acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(xf[1], wf[j][1], acc, ElemTraits<XEL>::HW, ElemTraits<WEL>::HW, 2, sx, 2, sw);
+            }
+        }
     }
 }
 
@@ -298,16 +319,32 @@ __device__ __forceinline__ void run_segment16(v4f &acc, const uint8_t *xl, int x
     const uint8_t *xrow = xl + (valid ? li : 0) * xp;
     const uint8_t *srow = sl + (valid ? li : 0) * sp;
     const int sh = 8 * h;
-    for (int s = wave; s < nslab; s += NW) {
-        const int sw = __builtin_amdgcn_raw_buffer_load_b32(rsw, sfw_off, s * 512, 0) >> sh;
-        const v8i wf = load_wfrag16<WEL>(rw, li * wrb, s, h);
-        int sx = 0;
-        v8i xf = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (valid) {
-            sx = (int)(*reinterpret_cast<const uint32_t *>(srow + 4 * s) >> sh);
-            xf = lds_xfrag16<XEL>(xrow + s * G<XEL>::BYTES, h);
+    constexpr int DEPTH = MM_DECODE_DEPTH;   // as run_segment
+    for (int s0 = wave; s0 < nslab; s0 += DEPTH * NW) {
+        v8i wf[DEPTH];
+        int swr[DEPTH];
+#pragma unroll
+        for (int j = 0; j < DEPTH; ++j) {
+            const int s = s0 + j * NW;
+            if (s < nslab) {
+                swr[j] = __builtin_amdgcn_raw_buffer_load_b32(rsw, sfw_off, s * 512, 0);
+                wf[j] = load_wfrag16<WEL>(rw, li * wrb, s, h);
+            }
         }
-        acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(xf, wf, acc, ElemTraits<XEL>::HW, ElemTraits<WEL>::HW, 0, sx, 0, sw);
+#pragma unroll
+        for (int j = 0; j < DEPTH; ++j) {
+            const int s = s0 + j * NW;
+            if (s < nslab) {
+                int sx = 0;
+                v8i xf = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (valid) {
+                    sx = (int)(*reinterpret_cast<const uint32_t *>(srow + 4 * s) >> sh);
+                    xf = lds_xfrag16<XEL>(xrow + s * G<XEL>::BYTES, h);
+                }
+                acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(xf, wf[j], acc, ElemTraits<XEL>::HW, ElemTraits<WEL>::HW, 0, sx, 0,
+                                                                       swr[j] >> sh);
+            }
+        }
     }
 }
 
