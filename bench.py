@@ -338,6 +338,26 @@ def main():
             few[f"q_o_M{m_}"] = {"M": m_, "N": N, "K": K, "split": list(fsplit), "kernel_us": round(us, 2), "kernel_us_stat": "median",
                                  "tflops": round(2.0 * m_ * N * K / us / 1e6, 1),
                                  "kernel": lib.mm_matmul_describe(m_, N, *fsplit, 1, 0, 0).decode()}
+        # ---- decode: one token through QLinearLayer.forward as ONE launch (mm_qlinear_decode: quantize + GEMM fused, M <= 8) ----
+        dec = {}
+        xd = x[:1].contiguous()
+        od = torch.empty((1, N), dtype=torch.bfloat16, device=dev)
+        stream_ptr = torch.cuda.current_stream().cuda_stream
+        wp = [t.data_ptr() if t.numel() else None for t in bf]
+        fd = lambda: lib.mm_qlinear_decode(xd.data_ptr(), idx.data_ptr(), *wp, 1, N, *fsplit, 1, 0, None, od.data_ptr(), stream_ptr)
+        assert fd() == 0
+        settle(fd, 0.2)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(200):
+            fd()
+        torch.cuda.synchronize()
+        t_dec = (time.perf_counter() - t0) / 200
+        wbytes = N * K // 2 + N * K // 32
+        dec["q_o_M1"] = {"M": 1, "N": N, "K": K, "split": list(fsplit), "us_per_launch": round(t_dec * 1e6, 2),
+                         "weight_stream_TBps": round(wbytes / t_dec / 1e12, 3),
+                         "note": "back-to-back launches through the C ABI (direct ctypes calls)"}
+        result["decode"] = dec
         del bf
         result["few_tiles"] = few
 
