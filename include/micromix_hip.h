@@ -205,20 +205,25 @@ const char *mm_matmul_describe(int M, int N, int KN, int KS, int KO, int wmode, 
 const char *mm_test_function(void);
 
 /*
- * Measurement hooks (used by bench.py and tools/gemm_clock.py; they change no result).  Both are THREAD-LOCAL: they affect
- * only launches made by the calling thread, so concurrent users of the library never see each other's hooks.
+ * Measurement hook -- UNSTABLE, not part of the drop-in interface (no reference counterpart; bench.py and tools/ use it; it changes
+ * no result).  THREAD-LOCAL: it affects only launches made by the calling thread.
  *
- * mm_diag_set_kernel_events: while a pair of hipEvent_t is registered, every tiled-GEMM launch (M > 64, and the M > 32 shapes that run on tiles) of this thread
- *   attaches them to its own dispatch (hipExtLaunchKernel start/stop events), so hipEventElapsedTime gives the kernel's
- *   duration as rocprofv3 reports it, without the launch gap that events recorded around the call include.  NULL, NULL disables.
- * mm_diag_set_clock_buffer: when a device buffer of 4 x 8 bytes per workgroup is registered, the large-M GEMM kernel stores
- *   {main-loop s_memtime delta, main-loop s_memrealtime delta, start tick, end-of-epilogue tick delta} of every workgroup
- *   there (in-kernel clock = ratio x 100 MHz); NULL disables.
- * The hardware microbenchmarks and probes (mm_diag_mfma, mm_diag_hw_convert, mm_diag_mfma_rate, mm_diag_l2_bw) are NOT part of
- * this library: they live in libmicromix_diag.so, declared in include/micromix_diag.h.
+ * mm_diag_set_kernel_events: while a pair of hipEvent_t is registered, every tiled-GEMM launch (M > 64, and the M > 32 shapes that
+ *   run on tiles) of this thread attaches them to its own dispatch (hipExtLaunchKernel start/stop events), so hipEventElapsedTime
+ *   gives the kernel's duration as rocprofv3 reports it, without the launch gap that events recorded around the call include.
+ *   NULL, NULL disables.  Host-side only: the kernels are the same with and without it.
+ *
+ * The in-kernel clock stamps (mm_diag_set_clock_buffer) and the MM_DBG ablation switches exist only in the instrumented
+ * developer variant of the library (-DMM_INSTRUMENT, csrc/mx_instrument.h, tools/build_variant.sh); the default library neither
+ * exports that symbol nor contains the stores.  The hardware microbenchmarks and probes (mm_diag_mfma, mm_diag_hw_convert,
+ * mm_diag_mfma_rate, mm_diag_l2_bw) live in libmicromix_diag.so, declared in include/micromix_diag.h.
  */
-int mm_diag_set_clock_buffer(void *buf);
 int mm_diag_set_kernel_events(void *start_event, void *stop_event);
+#ifdef MM_INSTRUMENT
+/* device buffer of 4 x 8 bytes per workgroup: {main-loop s_memtime delta, main-loop s_memrealtime delta, start tick,
+ * end-of-epilogue tick delta} of every workgroup of the large-M GEMM (in-kernel clock = ratio x 100 MHz); NULL disables. */
+int mm_diag_set_clock_buffer(void *buf);
+#endif
 
 #ifdef __cplusplus
 }

@@ -18,7 +18,7 @@ EXPORTS = (
     "mm_sf_bytes_x", "mm_sf_bytes_w", "mm_sf_offset",
     "mm_reorder_quantize", "mm_reorder_quantize_gather", "mm_activate_quantize", "mm_downproj_quantize", "mm_matmul",
     "mm_matmul_ws", "mm_matmul_workspace_bytes", "mm_rmsnorm_quantize", "mm_qlinear_decode", "mm_qlinear_decode_supported", "mm_matmul_grouped", "mm_reorder_quantize_grouped",
-    "mm_matmul_describe", "mm_test_function", "mm_diag_set_clock_buffer", "mm_diag_set_kernel_events",
+    "mm_matmul_describe", "mm_test_function", "mm_diag_set_kernel_events",
 )
 # every symbol include/micromix_diag.h declares (libmicromix_diag.so: hardware probes for tests/tools, never used by the ops)
 DIAG_LIB_PATH = os.environ.get("MICROMIX_DIAG_LIB") or os.path.join(_PKG, "lib", "libmicromix_diag.so")
@@ -99,8 +99,9 @@ def load():
     lib.mm_matmul_describe.argtypes = [i] * 7 + [ctypes.c_size_t]
     lib.mm_test_function.restype = ctypes.c_char_p
     lib.mm_test_function.argtypes = []
-    lib.mm_diag_set_clock_buffer.restype = i
-    lib.mm_diag_set_clock_buffer.argtypes = [vp]
+    if hasattr(lib, "mm_diag_set_clock_buffer"):      # only the -DMM_INSTRUMENT developer variant exports it (csrc/mx_instrument.h)
+        lib.mm_diag_set_clock_buffer.restype = i
+        lib.mm_diag_set_clock_buffer.argtypes = [vp]
     lib.mm_diag_set_kernel_events.restype = i
     lib.mm_diag_set_kernel_events.argtypes = [vp, vp]
     _lib = lib

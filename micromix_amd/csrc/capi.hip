@@ -325,9 +325,12 @@ int mm_diag_set_kernel_events(void *start_event, void *stop_event) {
     return MM_OK;
 }
 
+#ifdef MM_INSTRUMENT
+// only in the instrumented variant (csrc/mx_instrument.h): the default library has neither this symbol nor the in-kernel stores
 int mm_diag_set_clock_buffer(void *buf) {
     g_clock_buf = (unsigned long long *)buf;
     return MM_OK;
 }
+#endif
 
 }  // extern "C"

@@ -36,9 +36,7 @@
 #ifndef MM_FP4_KD256
 #define MM_FP4_KD256 1  // fp4 x fp4 segment on 256-deep slabs (whole cache lines per row); 0 = 128-deep slabs like the other segments
 #endif
-#ifndef MM_DBG
-#define MM_DBG 0  // kernel-developer ablation switches (results are garbage): 1 = no MFMA, 2 = no DMA, 512 = no fragment reads in the loop
-#endif
+#include "mx_instrument.h"   // MM_DBG ablation switches and MM_CLOCKS: constant 0 unless built with -DMM_INSTRUMENT
 #include "mx_common.h"
 #include "mx_kernels.h"
 

@@ -79,6 +79,61 @@ def test_split_k_matches_oracle(dev, wmode, rounding, m, n, k, split):
         check_gemm(got, qx, qw, rounding, label=f"{m}x{n}x{k} {split} {wmode} {rounding} split_k={split_k}")
 
 
+# Every K the reference binding compiles (mgemm/src/bindings.cpp:134-148: 3072, 3584, 4096, 5120, 8192, 11008, 12288, 13824,
+# 14336, 18944) reaches mm_matmul with a three-segment split, in both weight modes, on a weight-streaming launch (M = 8) and on a
+# tiled launch (M = 200); all rows against the oracle.
+REFERENCE_K = [(3072, (2048, 512, 512)), (3584, (2560, 512, 512)), (4096, (2048, 128, 1920)), (5120, (4096, 512, 512)),
+               (8192, (4096, 1024, 3072)), (11008, (9984, 896, 128)), (12288, (8192, 2048, 2048)), (13824, (12288, 1024, 512)),
+               (14336, (7168, 512, 6656)), (18944, (12544, 3200, 3200))]
+
+
+@pytest.mark.parametrize("wmode", ("w4", "w"))
+@pytest.mark.parametrize("k,split", REFERENCE_K, ids=[str(c[0]) for c in REFERENCE_K])
+def test_reference_compiled_k_values(dev, k, split, wmode):
+    rng = np.random.default_rng(k)
+    for m, n in ((8, 264), (200, 264)):
+        qx, qw = quantized(rng, m, n, k, split, wmode)
+        got = gpu_matmul(dev, qx, qw)
+        check_gemm(got, qx, qw, "reference", label=f"reference K={k} M={m} {split} {wmode}")
+
+
+def test_reference_smoke_shape_through_qlinear(dev):
+    """mgemm/test.py:6-27: M = 128, N = 3584, K = 11008, identity reorder index, its sign / magnitude distribution (including the
+    overlapping tail assignments at :14-20) and the split overridden to (0, 0, 11008) at :27; w4 weights (:35).  Run through
+    QLinearLayer and through the three ops, compared with the oracle on every row (the reference script asserts nothing: it
+    prints an MSE against the bf16 product)."""
+    import torch
+    from micromix_amd.qlinear import QLinearLayer
+    M, N, K = 128, 3584, 11008
+    g = torch.Generator().manual_seed(721)
+    kn, ks, ko = K - 1024, 1024 - 128, 128
+    signs = torch.randint(0, 2, (M, K), generator=g).to(torch.bfloat16) * 2 - 1
+    X = torch.rand((M, K), generator=g).to(torch.bfloat16) * 3
+    X[:, -kn:] = torch.rand((M, kn), generator=g).to(torch.bfloat16) * 8 + 8
+    X[:, -ks:] = torch.rand((M, ks), generator=g).to(torch.bfloat16) * 16 + 16
+    X[:, -ko:] = torch.rand((M, ko), generator=g).to(torch.bfloat16) * 32 + 32
+    X = (X * signs).to(dev)
+    W = torch.rand((N, K), generator=g).to(torch.bfloat16).to(dev)
+    idx = torch.arange(K, dtype=torch.int16, device=dev)
+    split = (0, 0, K)
+    a = mixedgemm.reorder_quantize_x(X, idx, *split)
+    b = mixedgemm.reorder_quantize_w4(W, idx, *split)
+    C = mixedgemm.matmul(a[0], b[0], a[1], b[1], a[2], b[2], a[3], b[3], a[4], b[4], a[5], b[5])
+    qx = o.reorder_quantize(bits_from_t(X), u8(idx), *split, "x")
+    qw = o.reorder_quantize(bits_from_t(W), u8(idx), *split, "w4")
+    for i in range(6):
+        assert np.array_equal(u8(a[i]), qx[i]) and np.array_equal(u8(b[i]), qw[i]), f"quantizer output {i} differs from the oracle"
+    check_gemm(bits_from_t(C), qx, qw, "reference", label="mgemm/test.py shape", strict=True)
+    lin = torch.nn.Linear(K, N, bias=False, dtype=torch.bfloat16, device=dev)
+    with torch.no_grad():
+        lin.weight.copy_(W)
+    layer = QLinearLayer(lin, p8_num=K, p6_num=0, reorder_index=idx.long())
+    assert torch.equal(layer(X), C)
+    # the script's own figure of merit: MSE against the unquantised product, relative to the output variance
+    D = X.float() @ W.float().t()
+    assert float(((C.float() - D) ** 2).mean() / D.var()) < 5e-2      # MXFP4 weights: ~1e-2 expected from the fp4 grid alone
+
+
 def test_split_k_is_deterministic_and_keeps_bias(dev):
     import torch
     rng = np.random.default_rng(77)
@@ -207,11 +262,15 @@ def test_full_size_properties(dev):
             r0, r1 = 1000, 1100
             sub = mixedgemm.reorder_quantize_x(x[r0:r1].contiguous(), tidx, *split)
             assert torch.equal(mixedgemm.matmul(*args(sub)), d1[r0:r1])
-            # oracle on a sample of rows
+            # oracle on a sample of rows, with the asserted ulp statistics, in both rounding modes: this is the exact shape,
+            # split and kernel bench.py times
             rows = np.sort(rng.choice(M, 48, replace=False))
             qx = o.reorder_quantize(xb[rows], idx, *split, "x")
             qw = [u8(t) for t in b]
-            check_gemm(bits_from_t(d1)[rows], qx, qw, "reference", label=f"4096^3 {split}")
+            wdeq = o.dequant_operand(qw, "w", "w4" if fn is mixedgemm.reorder_quantize_w4 else "w")
+            check_gemm(bits_from_t(d1)[rows], qx, qw, "reference", label=f"4096^3 {split} {fn.__name__}", strict=True, wdeq=wdeq)
+            df = mixedgemm.matmul(*args(a), rounding="fused")
+            check_gemm(bits_from_t(df)[rows], qx, qw, "fused", label=f"4096^3 {split} {fn.__name__} fused", strict=True, wdeq=wdeq)
 
 
 # one problem per tile kernel of mx_gemm256.hip (the dispatch is asserted, so a change of plan_tiles cannot silently drop one):

@@ -24,6 +24,7 @@ from oracle import mx_oracle as o
 pytestmark = pytest.mark.gpu
 
 LLAMA = [
+    ("q_o", 4096, 4096, (0, 0, 4096)), ("q_o", 4096, 4096, (4096, 0, 0)),       # the bench headline (BASELINE configs[1]) and all-fp4
     ("q_o", 4096, 4096, (2048, 128, 1920)), ("q_o", 4096, 4096, (3072, 896, 128)),
     ("k_v", 1024, 4096, (2048, 128, 1920)), ("k_v", 1024, 4096, (3072, 896, 128)), ("k_v", 1024, 4096, (0, 0, 4096)),
     ("gate_up", 14336, 4096, (2048, 128, 1920)), ("gate_up", 14336, 4096, (3072, 896, 128)), ("gate_up", 14336, 4096, (0, 0, 4096)),

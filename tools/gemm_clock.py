@@ -2,13 +2,19 @@
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+# the clock stamps exist only in the instrumented variant (csrc/mx_instrument.h): tools/build_variant.sh instr -DMM_INSTRUMENT
+if "MICROMIX_HIP_LIB" not in os.environ:
+    os.environ["MICROMIX_HIP_LIB"] = os.path.join(ROOT, "micromix_amd", "lib", "dbg", "lib_instr.so")
+if not os.path.exists(os.environ["MICROMIX_HIP_LIB"]):
+    sys.exit("build the instrumented library first: tools/build_variant.sh instr -DMM_INSTRUMENT")
 import torch
 import bench
 from micromix_amd import _lib, mixedgemm
 lib = _lib.load(); dev = torch.device("cuda:0")
 tag = os.path.basename(os.environ.get("MICROMIX_HIP_LIB", "default"))
-x, w, idx = [t.to(dev) for t in bench.synth_inputs()]
-N = K = 4096
+N = 4096
+K = next((int(a[2:]) for a in sys.argv[1:] if a.startswith("K=")), 4096)   # K=<depth>: e.g. K=14336 for down_proj splits
+x, w, idx = [t.to(dev) for t in bench.synth_inputs(0 if K == 4096 else 1, 4096, N, K)]
 M = next((int(a[2:]) for a in sys.argv[1:] if a.startswith("M=")), 4096)   # M=<rows>: the first rows of the bench activations
 x = x[:M].contiguous()
 out = torch.empty((M, N), dtype=torch.bfloat16, device=dev)

@@ -1,5 +1,6 @@
 """Small fixed workload for the rocprofv3 passes: 10 x (reorder_quantize_x + matmul) per split on the 4096^3 bench shape, w4
-weights.  `python tools/pmc_target.py [KN,KS,KO ...]` (default: the bench split (0,0,4096))."""
+weights.  `python tools/pmc_target.py [KN,KS,KO[@MxNxK] ...]` (default: the bench split (0,0,4096); @MxNxK = another shape, e.g.
+12288,1024,1024@4096x4096x14336 for down_proj)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -7,9 +8,12 @@ import torch
 import bench
 from micromix_amd import mixedgemm
 dev = torch.device("cuda:0")
-x, w, idx = [t.to(dev) for t in bench.synth_inputs()]
-splits = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]] or [bench.SPLIT]
-for split in splits:
+args = sys.argv[1:] or [",".join(str(v) for v in bench.SPLIT)]
+for arg in args:
+    sp, _, shape = arg.partition("@")
+    split = tuple(int(v) for v in sp.split(","))
+    m, n, k = (int(v) for v in shape.split("x")) if shape else (bench.M, bench.N, bench.K)
+    x, w, idx = [t.to(dev) for t in bench.synth_inputs(0 if not shape else 1, m, n, k)]
     b = mixedgemm.reorder_quantize_w4(w, idx, *split)
     for _ in range(10):
         a = mixedgemm.reorder_quantize_x(x, idx, *split)
