@@ -60,9 +60,15 @@ enum mm_matmul_flags {
     MM_ROUND_PER_SEGMENT = 0, /* default: accumulator rounded through bf16 after each segment, as the
                                  reference's three chained kernels do (gemm.cu:75-77) */
     MM_ROUND_ONCE = 1,        /* single fp32 accumulator across segments, one bf16 rounding */
-    MM_SPLIT_K_ALWAYS = 2     /* mm_matmul_ws: split K whenever the shape allows it, not only where the cost model expects a
+    MM_SPLIT_K_ALWAYS = 2,    /* mm_matmul_ws: split K whenever the shape allows it, not only where the cost model expects a
                                  gain (tests and tuning) */
+    MM_WS_TICKETS_ZEROED = 4  /* mm_matmul_ws / mm_matmul_workspace_bytes / mm_matmul_describe: the first MM_WS_TICKET_BYTES of the
+                                 workspace are ZERO (the caller cleared them once, when it created the workspace; every launch
+                                 leaves them zero again).  Enables the split-K whose reduction runs inside the GEMM launch (64-row
+                                 tiles, launches with few tiles): its workgroups count their arrivals per tile there.  Without the
+                                 flag the workspace may hold anything, and that path is not taken. */
 };
+#define MM_WS_TICKET_BYTES 4096
 
 int mm_version(void); /* major * 10000 + minor * 100 + patch */
 const char *mm_strerror(int status);

@@ -134,7 +134,7 @@ int mm_qlinear_decode(const void *X_bf16, const int16_t *reorder_index, const ui
 size_t mm_matmul_workspace_bytes(int M, int N, int KN, int KS, int KO, int wmode, int flags) {
     if (M <= 0 || N <= 0 || KN < 0 || KS < 0 || KO < 0 || (KN % 128) || (KS % 128) || (KO % 128)) return 0;
     const int K[3] = {KN, KS, KO};
-    return mm::mx_gemm_workspace_bytes(M, N, K, wmode == MM_W_FP4, (flags & MM_SPLIT_K_ALWAYS) != 0);
+    return mm::mx_gemm_workspace_bytes(M, N, K, wmode == MM_W_FP4, (flags & MM_SPLIT_K_ALWAYS) != 0, (flags & MM_WS_TICKETS_ZEROED) != 0);
 }
 
 const char *mm_matmul_describe(int M, int N, int KN, int KS, int KO, int wmode, int flags, size_t workspace_bytes) {
@@ -142,7 +142,7 @@ const char *mm_matmul_describe(int M, int N, int KN, int KS, int KO, int wmode, 
     const int K[3] = {KN, KS, KO};
     if (M <= 64 && !mm::mx_gemm_small_m_uses_tiles(M, N, K, wmode == MM_W_FP4, workspace_bytes, (flags & MM_SPLIT_K_ALWAYS) != 0))
         return "mm::skinny::mx_gemm_skinny*_kernel (weight streaming, M <= 64)";
-    return mm::describe_mx_gemm256(M, N, K, wmode == MM_W_FP4, workspace_bytes, (flags & MM_SPLIT_K_ALWAYS) != 0);
+    return mm::describe_mx_gemm256(M, N, K, wmode == MM_W_FP4, workspace_bytes, (flags & MM_SPLIT_K_ALWAYS) != 0, (flags & MM_WS_TICKETS_ZEROED) != 0);
 }
 
 int mm_matmul(const uint8_t *AN, const uint8_t *BN, const uint8_t *AS, const uint8_t *BS, const uint8_t *AO,
@@ -190,6 +190,8 @@ int mm_matmul_ws(const uint8_t *AN, const uint8_t *BN, const uint8_t *AS, const 
     a.ws = (float *)workspace;
     a.ws_bytes = workspace ? workspace_bytes : 0;
     a.splits = 0;
+    a.tickets = nullptr;
+    a.tickets_zeroed = (workspace && (flags & MM_WS_TICKETS_ZEROED)) ? 1 : 0;
     a.n_tile0 = a.n_tiles = 0;
     a.force_split = (flags & MM_SPLIT_K_ALWAYS) ? 1 : 0;
     a.split_first[0] = a.split_first[1] = a.split_first[2] = a.split_first[3] = 0;
@@ -268,6 +270,7 @@ int mm_matmul_grouped(const mm_group *groups, int ngroups, int N, int KN, int KS
         a.clock_out = nullptr;
         a.ev_start = a.ev_stop = nullptr;
         a.ws = nullptr; a.ws_bytes = 0; a.splits = 0; a.force_split = 0; a.n_tile0 = a.n_tiles = 0;
+        a.tickets = nullptr; a.tickets_zeroed = 0;
         a.split_first[0] = a.split_first[1] = a.split_first[2] = a.split_first[3] = 0;
     };
     if (KN + KS + KO == 0) {   // no segment: every output is zero (gemm.cu:48-50)

@@ -50,6 +50,9 @@ namespace mm {
 #define MM_DEVICE_ONLY(...)
 #endif
 
+// in-kernel split-K (split_tile_reduce): scope of the ticket atomics and cache-policy bits of the partial-sum traffic
+#define MM_SPLIT_SCOPE __HIP_MEMORY_SCOPE_AGENT
+#define MM_SPLIT_AUX 16   // sc1 = device scope
 #define MM_NS g256
 #define MM_MAX_STAGES 3
 #define MM_LDS_BUDGET (160 * 1024)
@@ -250,12 +253,72 @@ static int plan_splits(int M, int N, const int K[3], bool w4, bool force, int fi
     return first[3];
 }
 
-size_t mx_gemm_workspace_bytes(int M, int N, const int K[3], bool w4, bool force) {
+// ---------------------------------------------------------------------------------------------------------
+// In-kernel split-K of the 4-wave tiles (split_tile_reduce in mx_gemm_tile.inc): a launch whose 64 x 64 tiles occupy at most a
+// quarter of the CUs cuts K into `splits` equal slab ranges, one workgroup each, and the last workgroup of a tile to finish
+// reduces.  Workspace: [tickets: MM_TICKET_BYTES, one 32-bit counter per tile, zero between launches][tiles x (<= splits + 2)
+// partial-sum slots].
+// What it is worth, measured on MI355X (tools/split_clock.py: kernel durations from dispatch events, phases from in-kernel clock
+// stamps; k/v projection N = 1024, K = 4096, M = 128, 32 tiles): unsplit 12.7 us; 2 / 4 / 6 / 8 splits 12.3 / 11.2 / 10.2 / 15.6 us.
+// A workgroup needs ~2.5-3.5 us from its start to its first finished slab and ~0.3 us per 128-deep slab after that; the split
+// adds ~0.6 us (partial sums acknowledged, ticket) and one round trip of ~2 us for the reducing workgroup's reads (the partial
+// sums are written through to memory: the eight XCDs' L2s are not coherent for plain accesses), so at K = 4096 a split saves at
+// most the slabs it removes minus ~3 us -- 2-2.5 us of 12.7 with six splits -- and nothing once the tiles alone fill half of
+// the chip (q/o, N = 4096, M = 128: 128 tiles, unsplit 12.9 us, 2 splits 14.1 us); with all 256 CUs busy loading it loses
+// (8 splits x 32 tiles: 15.6 us), and with 64 tiles (k/v at M = 256) two to four splits land within +-0.7 us of the unsplit
+// 12.3 us.  Hence the rule below: at most 48 tiles, four to six splits, at most 192 workgroups, at least four slabs per split.  MICROMIX_SPLIT_SMALL=0 disables it, =<tile>:<S> (tile 33 = 64 x 64, 32 = 64 x 128) pins a plan
+// (tools, tests); MM_SPLIT_K_ALWAYS relaxes the rule to "any split that fits one round of workgroups".
+// ---------------------------------------------------------------------------------------------------------
+struct SmallSplit {
+    int kind;     // 0 = none, 33 = 64 x 64 tiles, 32 = 64 x 128 tiles
+    int splits;
+    int tiles;
+};
+constexpr size_t small_part_bytes(int kind) { return kind == 33 ? (size_t)g32n::NACC * g32n::NT * 4 : (size_t)g32::NACC * g32::NT * 4; }
+constexpr size_t MM_TICKET_BYTES = 4096;   // = mm_matmul_ticket_bytes(): room for 1024 tiles (a launch of this kind has at most CUs / 2)
+static size_t small_ticket_bytes(int) { return MM_TICKET_BYTES; }
+// a split leaves one partial sum per segment it touches: at most splits + 2 slots per tile
+static size_t small_split_bytes(const SmallSplit &p) { return p.kind ? small_ticket_bytes(p.tiles) + (size_t)p.tiles * (p.splits + 2) * small_part_bytes(p.kind) : 0; }
+
+static SmallSplit plan_small_split(int M, int N, const int K[3], bool force) {
+    SmallSplit none{0, 0, 0};
+    static const char *pin = getenv("MICROMIX_SPLIT_SMALL");
+    if (M <= 64 || (pin && pin[0] == '0' && pin[1] == 0)) return none;   // (M <= 64: the weight-streaming kernels, mx_gemm.hip)
+    const int cus = device_cus();
+    const int total = (K[0] >> 7) + (K[1] >> 7) + (K[2] >> 7);
+    const int t32n = ((M + 63) / 64) * ((N + 63) / 64), t32 = ((M + 63) / 64) * ((N + 127) / 128);
+    if (pin && pin[0]) {
+        int kind = 0, S = 0;
+        if (sscanf(pin, "%d:%d", &kind, &S) == 2 && (kind == 33 || kind == 32) && S >= 2 && S <= MM_MAX_SPLITS && S <= total)
+            return SmallSplit{kind, S, kind == 33 ? t32n : t32};
+        return none;
+    }
+    if (force) {    // tests: the most splits that fit one round of workgroups, 64 x 64 tiles while those fit, else 64 x 128
+        for (int kind : {33, 32}) {
+            const int tiles = kind == 33 ? t32n : t32;
+            int S = cus / (tiles > 0 ? tiles : 1);
+            S = S > MM_MAX_SPLITS ? MM_MAX_SPLITS : S;
+            S = S > total / 2 ? total / 2 : S;
+            if (S >= 2) return SmallSplit{kind, S, tiles};
+        }
+        return none;
+    }
+    if (t32n > 48) return none;
+    int S = 192 / t32n;
+    S = S > 6 ? 6 : S;
+    S = S > total / 4 ? total / 4 : S;
+    return S >= 4 ? SmallSplit{33, S, t32n} : none;
+}
+
+size_t mx_gemm_workspace_bytes(int M, int N, const int K[3], bool w4, bool force, bool tickets_zeroed) {
+    const SmallSplit sp = tickets_zeroed ? plan_small_split(M, N, K, force) : SmallSplit{0, 0, 0};
+    if (sp.kind) return small_split_bytes(sp);
     int first[4];
     const int S = plan_splits(M, N, K, w4, force, first);
     if (S == 0) return 0;
     const size_t tiles = (size_t)((M + g128::BM - 1) / g128::BM) * ((N + g128::BN - 1) / g128::BN);
-    return tiles * S * SPLIT_WG_FLOATS * sizeof(float);
+    // with MM_WS_TICKETS_ZEROED the head of the workspace belongs to the ticket counters: the partial sums start behind it
+    return (tickets_zeroed ? MM_TICKET_BYTES : 0) + tiles * S * SPLIT_WG_FLOATS * sizeof(float);
 }
 
 template <class KernelT>
@@ -270,14 +333,15 @@ static hipError_t launch_tile(KernelT kern, DynamicLdsOnce &attr, int lds_bytes,
 }
 
 // Which kernel(s) a problem runs on: decided once here, used by the launcher and by mm_matmul_describe.
-enum TileKind { TK_SPLITK, TK_G64, TK_G256_TAIL, TK_G256, TK_G128, TK_G32, TK_G32N };
+enum TileKind { TK_SPLITK, TK_SMALL_SPLIT, TK_G64, TK_G256_TAIL, TK_G256, TK_G128, TK_G32, TK_G32N };
 struct TilePlan {
     TileKind kind;
     int tn, tiles256, tiles128, tiles64, tiles32, tiles32n, tm256, tm128, tail_cols;
     int splits, split_first[4];
+    SmallSplit small;
 };
 
-static TilePlan plan_tiles(int M, int N, const int K[3], bool w4, bool have_ws, size_t ws_bytes, bool force_split) {
+static TilePlan plan_tiles(int M, int N, const int K[3], bool w4, bool have_ws, size_t ws_bytes, bool force_split, bool tickets_zeroed) {
     TilePlan p{};
     p.tn = (N + 255) / 256;
     p.tm256 = (M + 255) / 256;
@@ -288,8 +352,15 @@ static TilePlan plan_tiles(int M, int N, const int K[3], bool w4, bool have_ws, 
     p.tiles32 = ((M + 63) / 64) * ((N + 127) / 128);
     p.tiles32n = ((M + 63) / 64) * ((N + 63) / 64);
     if (have_ws) {
+        p.small = tickets_zeroed ? plan_small_split(M, N, K, force_split) : SmallSplit{0, 0, 0};
+        if (p.small.kind && p.small.tiles * 4 <= (int)MM_TICKET_BYTES && small_split_bytes(p.small) <= ws_bytes) {
+            p.kind = TK_SMALL_SPLIT;
+            p.splits = p.small.splits;
+            return p;
+        }
+        p.small = SmallSplit{0, 0, 0};
         p.splits = plan_splits(M, N, K, w4, force_split, p.split_first);
-        if (p.splits && (size_t)p.tiles128 * p.splits * SPLIT_WG_FLOATS * sizeof(float) <= ws_bytes) {
+        if (p.splits && (tickets_zeroed ? MM_TICKET_BYTES : 0) + (size_t)p.tiles128 * p.splits * SPLIT_WG_FLOATS * sizeof(float) <= ws_bytes) {
             p.kind = TK_SPLITK;
             return p;
         }
@@ -345,16 +416,17 @@ bool mx_gemm_small_m_uses_tiles(int M, int N, const int K[3], bool w4, size_t ws
     if (M <= 32 || M > 64) return M > 64;
     if ((N + 31) / 32 > device_cus()) return true;
     if (ws_bytes == 0) return false;
-    const size_t need = mx_gemm_workspace_bytes(M, N, K, w4, force_split);
+    const size_t need = mx_gemm_workspace_bytes(M, N, K, w4, force_split, false);   // (the in-kernel split starts above M = 64)
     return need > 0 && need <= ws_bytes;
 }
 
-const char *describe_mx_gemm256(int M, int N, const int K[3], bool w4, size_t ws_bytes, bool force_split) {
+const char *describe_mx_gemm256(int M, int N, const int K[3], bool w4, size_t ws_bytes, bool force_split, bool tickets_zeroed) {
     static thread_local char buf[192];
-    const TilePlan p = plan_tiles(M, N, K, w4, ws_bytes > 0, ws_bytes, force_split);
+    const TilePlan p = plan_tiles(M, N, K, w4, ws_bytes > 0, ws_bytes, force_split, tickets_zeroed);
     const char *w = w4 ? "true" : "false";
     switch (p.kind) {
         case TK_SPLITK: snprintf(buf, sizeof(buf), "mm::g128::mx_gemm256_kernel<%s,true> x %d workgroups (128x256 tiles, split-K %d) + mm::splitk_reduce_kernel", w, p.tiles128 * p.splits, p.splits); break;
+        case TK_SMALL_SPLIT: snprintf(buf, sizeof(buf), "mm::%s::mx_gemm256_kernel<%s,true> x %d workgroups (%s tiles, in-kernel split-K %d)", p.small.kind == 33 ? "g32n" : "g32", w, p.small.tiles * p.small.splits, p.small.kind == 33 ? "64x64" : "64x128", p.small.splits); break;
         case TK_G64: snprintf(buf, sizeof(buf), "mm::g64::mx_gemm256_kernel<%s,false> x %d workgroups (128x128 tiles)", w, p.tiles64); break;
         case TK_G32: snprintf(buf, sizeof(buf), "mm::g32::mx_gemm256_kernel<%s,false> x %d workgroups (64x128 tiles)", w, p.tiles32); break;
         case TK_G32N: snprintf(buf, sizeof(buf), "mm::g32n::mx_gemm256_kernel<%s,false> x %d workgroups (64x64 tiles)", w, p.tiles32n); break;
@@ -367,11 +439,12 @@ const char *describe_mx_gemm256(int M, int N, const int K[3], bool w4, size_t ws
 
 hipError_t launch_mx_gemm256(const GemmArgs &a, bool w4, hipStream_t stream) {
     static DynamicLdsOnce done[12];
-    const TilePlan p = plan_tiles(a.M, a.N, a.K, w4, a.ws != nullptr, a.ws_bytes, a.force_split != 0);
+    const TilePlan p = plan_tiles(a.M, a.N, a.K, w4, a.ws != nullptr, a.ws_bytes, a.force_split != 0, a.tickets_zeroed != 0);
     switch (p.kind) {
         case TK_SPLITK: {
             GemmArgs b = a;
             b.splits = p.splits;
+            if (a.tickets_zeroed) b.ws = reinterpret_cast<float *>(reinterpret_cast<uint8_t *>(a.ws) + MM_TICKET_BYTES);   // the ticket counters stay zero
             for (int i = 0; i < 4; ++i) b.split_first[i] = p.split_first[i];
             hipError_t e = w4 ? launch_tile(g128::mx_gemm256_kernel<true, true>, done[4], g128::Lds<true>::TOTAL, p.tiles128 * p.splits, g128::NT, b, stream)
                               : launch_tile(g128::mx_gemm256_kernel<false, true>, done[5], g128::Lds<false>::TOTAL, p.tiles128 * p.splits, g128::NT, b, stream);
@@ -379,6 +452,40 @@ hipError_t launch_mx_gemm256(const GemmArgs &a, bool w4, hipStream_t stream) {
             const int total = p.tiles128 * SPLIT_WG_FLOATS;
             hipLaunchKernelGGL(splitk_reduce_kernel, dim3((total / 4 + 255) / 256), dim3(256), 0, stream, b, p.tn, total);
             return hipGetLastError();
+        }
+        case TK_SMALL_SPLIT: {
+            GemmArgs b = a;
+            b.splits = p.small.splits;
+            b.tickets = reinterpret_cast<unsigned *>(a.ws);
+            b.ws = reinterpret_cast<float *>(reinterpret_cast<uint8_t *>(a.ws) + small_ticket_bytes(p.small.tiles));
+            {
+                // equal slab ranges; a cut inside the fp4 segment moves down to an even unit (256-deep slabs stay whole lines)
+                // when that leaves the range before it non-empty
+                const int n0s = a.K[0] >> 7, total = n0s + (a.K[1] >> 7) + (a.K[2] >> 7), S = p.small.splits;
+                for (int q = 0; q <= S; ++q) {
+                    int c = (int)((long long)total * q / S);
+                    if (c < n0s && (c & 1) && q > 0 && q < S && c - 1 > b.split_cut[q - 1]) c -= 1;
+                    b.split_cut[q] = (unsigned short)c;
+                }
+                const int off[4] = {0, n0s, n0s + (a.K[1] >> 7), total};
+                int slot = 0;
+                b.slot_seg = 0;
+                for (int q = 0; q < S; ++q) {
+                    b.split_slot[q] = (unsigned short)slot;
+                    for (int sg = 0; sg < 3; ++sg) {
+                        const int lo = b.split_cut[q] > off[sg] ? b.split_cut[q] : off[sg], hi = b.split_cut[q + 1] < off[sg + 1] ? b.split_cut[q + 1] : off[sg + 1];
+                        if (hi > lo) b.slot_seg |= (unsigned long long)sg << (2 * slot++);
+                    }
+                }
+                b.split_slot[S] = (unsigned short)slot;
+            }
+            const int wgs = p.small.tiles * p.small.splits;
+            static DynamicLdsOnce sdone[4];
+            if (p.small.kind == 33)
+                return w4 ? launch_tile(g32n::mx_gemm256_kernel<true, true>, sdone[0], g32n::Lds<true>::TOTAL, wgs, g32n::NTHREADS, b, stream)
+                          : launch_tile(g32n::mx_gemm256_kernel<false, true>, sdone[1], g32n::Lds<false>::TOTAL, wgs, g32n::NTHREADS, b, stream);
+            return w4 ? launch_tile(g32::mx_gemm256_kernel<true, true>, sdone[2], g32::Lds<true>::TOTAL, wgs, g32::NTHREADS, b, stream)
+                      : launch_tile(g32::mx_gemm256_kernel<false, true>, sdone[3], g32::Lds<false>::TOTAL, wgs, g32::NTHREADS, b, stream);
         }
         case TK_G64:
             if (w4) return launch_tile(g64::mx_gemm256_kernel<true, false>, done[6], g64::Lds<true>::TOTAL, p.tiles64, g64::NT, a, stream);

@@ -37,6 +37,8 @@ struct DynamicLdsOnce {
     }
 };
 
+constexpr int MM_MAX_SPLITS = 16;   // in-kernel split-K: splits per tile
+
 struct GemmArgs {
     const uint8_t *X[3];    // activation segments  (AN, AS, AO)
     const uint8_t *W[3];    // weight segments      (BN, BS, BO)
@@ -55,6 +57,11 @@ struct GemmArgs {
     int n_tile0, n_tiles;   // launcher: this launch covers 256-feature tile columns [n_tile0, n_tile0 + n_tiles) (0, 0 = all)
     int splits;             // filled in by the launcher when it splits K
     int split_first[4];     // splits [split_first[i], split_first[i+1]) work on segment i
+    unsigned short split_cut[MM_MAX_SPLITS + 1];   // in-kernel split-K: split q walks 128-deep K units [split_cut[q], split_cut[q+1]) of N | S | O
+    unsigned short split_slot[MM_MAX_SPLITS + 1];  // ... and leaves its partial sums in slots split_slot[q] ... of its tile; [splits] = slots per tile
+    unsigned long long slot_seg;    // ... two bits per slot: the segment (0 N, 1 S, 2 O) whose partial sum the slot holds
+    unsigned *tickets;              // in-kernel split-K (4-wave tiles): one counter per tile at the head of the workspace, zero between launches
+    int tickets_zeroed;             // MM_WS_TICKETS_ZEROED: the caller vouches for that
     hipEvent_t ev_start, ev_stop;   // diagnostics only (mm_diag_set_kernel_events): recorded at the GEMM dispatch itself
     unsigned long long *clock_out;  // diagnostics only (mm_diag_set_clock_buffer): per workgroup {shader cycles, 100 MHz ticks}
 };
@@ -101,8 +108,8 @@ hipError_t launch_mx_gemm(const GemmArgs &a, bool w4, hipStream_t stream);
 hipError_t launch_mx_gemm256(const GemmArgs &a, bool w4, hipStream_t stream);
 hipError_t launch_mx_gemm_skinny(const GemmArgs &a, bool w4, hipStream_t stream);
 hipError_t launch_mx_gemm_skinny_grouped(const GroupedGemmArgs &ga, int max_m, bool w4, hipStream_t stream);
-size_t mx_gemm_workspace_bytes(int M, int N, const int K[3], bool w4, bool force);
+size_t mx_gemm_workspace_bytes(int M, int N, const int K[3], bool w4, bool force, bool tickets_zeroed);
 bool mx_gemm_small_m_uses_tiles(int M, int N, const int K[3], bool w4, size_t ws_bytes, bool force_split);
-const char *describe_mx_gemm256(int M, int N, const int K[3], bool w4, size_t ws_bytes, bool force_split);   // thread-local buffer  // 0 when mm_matmul would not split K for this shape
+const char *describe_mx_gemm256(int M, int N, const int K[3], bool w4, size_t ws_bytes, bool force_split, bool tickets_zeroed);   // thread-local buffer  // 0 when mm_matmul would not split K for this shape
 
 }  // namespace mm

@@ -143,6 +143,22 @@ def reorder_quantize_w4(W, reorder_index, KN, KS, KO):
     return _quantize(W, reorder_index, KN, KS, KO, "w4", "reorder_quantize_w4")
 
 
+_SPLIT_WS = {}
+
+
+def split_workspace(dev, nbytes):
+    """The split-K scratch of `dev`'s current stream: one tensor per (device, stream), grown when a shape needs more, its first
+    MM_WS_TICKET_BYTES zero (the C ABI's MM_WS_TICKETS_ZEROED contract: cleared once here, left zero by every launch).  Reuse by
+    consecutive launches of one stream is ordered by the stream; the C ABI itself never allocates."""
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    t = _SPLIT_WS.get(key)
+    if t is None or t.numel() < nbytes:
+        t = torch.empty((max(int(nbytes), 8 << 20),), dtype=torch.uint8, device=dev)
+        t[:_lib.MM_WS_TICKET_BYTES].zero_()
+        _SPLIT_WS[key] = t
+    return t
+
+
 def matmul(AN, BN, AS, BS, AO, BO, SFAN, SFBN, SFAS, SFBS, SFAO, SFBO, *, bias=None, rounding="reference", out=None,
            split_k=True):
     """bindings.cpp:50-102.  Returns a new [M, N] bf16 tensor.
@@ -215,9 +231,11 @@ def matmul(AN, BN, AS, BS, AO, BO, SFAN, SFBN, SFAS, SFBS, SFAO, SFBO, *, bias=N
     if split_k and M > 32:
         if split_k == "force":
             flags |= _lib.MM_SPLIT_K_ALWAYS
+        flags |= _lib.MM_WS_TICKETS_ZEROED
         ws_bytes = lib.mm_matmul_workspace_bytes(M, N, KN, KS, KO, wmode, flags)
         if ws_bytes:
-            ws = torch.empty((ws_bytes,), dtype=u8, device=dev)
+            ws = split_workspace(dev, ws_bytes)
+            ws_bytes = ws.numel()
     with _on_device(index):
         st = lib.mm_matmul_ws(_ptr(AN), _ptr(BN), _ptr(AS), _ptr(BS), _ptr(AO), _ptr(BO), _ptr(SFAN), _ptr(SFBN),
                               _ptr(SFAS), _ptr(SFBS), _ptr(SFAO), _ptr(SFBO), M, N, KN, KS, KO, wmode, flags,

@@ -79,15 +79,18 @@ class _DecodePlan:
         for sz in sizes:
             offs.append(total)
             total += (sz + 255) & ~255
+        from . import _lib
+        wflags = self.flags | _lib.MM_WS_TICKETS_ZEROED     # the split-K scratch is mixedgemm.split_workspace (ticket words kept zero)
         ws_bytes = self.ws_bytes.get(m)
         if ws_bytes is None:
-            ws_bytes = self.ws_bytes[m] = self.lib.mm_matmul_workspace_bytes(m, self.n, kn, ks, ko, self.wmode, self.flags) if m > 32 else 0
+            ws_bytes = self.ws_bytes[m] = self.lib.mm_matmul_workspace_bytes(m, self.n, kn, ks, ko, self.wmode, wflags) if m > 32 else 0
         if torch.cuda.current_device() != self.index:
             with torch.cuda.device(self.index):
                 return self.run_two_op(x2d, bias)
-        # one scratch tensor: quantizer outputs + split-K workspace; it is released at return, which is safe because the
-        # caching allocator only hands the block to later work on the same stream
-        scratch = torch.empty((total + ws_bytes,), dtype=torch.uint8, device=self.device)
+        # one scratch tensor for the quantizer outputs; it is released at return, which is safe because the caching allocator only
+        # hands the block to later work on the same stream.  The split-K workspace is the stream's persistent one.
+        scratch = torch.empty((total,), dtype=torch.uint8, device=self.device)
+        ws = mixedgemm.split_workspace(self.device, ws_bytes) if ws_bytes else None
         base = scratch.data_ptr()
         q = [base + o if sz else None for o, sz in zip(offs, sizes)]
         out = torch.empty((m, self.n), dtype=torch.bfloat16, device=self.device)
@@ -96,10 +99,9 @@ class _DecodePlan:
         st = self.lib.mm_reorder_quantize(x2d.data_ptr(), m, self.k, idx, kn, ks, ko, 0, *q, stream)
         if st == 0:
             st = self.lib.mm_matmul_ws(q[0], bn, q[1], bs, q[2], bo, q[3], sfbn, q[4], sfbs, q[5], sfbo, m, self.n, kn, ks, ko,
-                                       self.wmode, self.flags, bias.data_ptr() if bias is not None else None, out.data_ptr(),
-                                       base + total if ws_bytes else None, ws_bytes, stream)
+                                       self.wmode, wflags, bias.data_ptr() if bias is not None else None, out.data_ptr(),
+                                       ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0, stream)
         if st:
-            from . import _lib
             _lib.check(st, "QLinearLayer.forward")
         return out
 

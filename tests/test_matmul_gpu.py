@@ -146,7 +146,8 @@ def test_split_k_is_deterministic_and_keeps_bias(dev):
     runs = [gpu_matmul(dev, qx, qw, bias=bias, split_k="force") for _ in range(3)]
     assert np.array_equal(runs[0], runs[1]) and np.array_equal(runs[0], runs[2])
     a, b = to_dev(dev, qx), to_dev(dev, qw)
-    plain = mixedgemm.matmul(a[0], b[0], a[1], b[1], a[2], b[2], a[3], b[3], a[4], b[4], a[5], b[5])
+    # the bias epilogue of the split path = the same split product plus a separate add (qLinearLayer.py:68-71)
+    plain = mixedgemm.matmul(a[0], b[0], a[1], b[1], a[2], b[2], a[3], b[3], a[4], b[4], a[5], b[5], split_k="force")
     assert np.array_equal(runs[0], bits_from_t(plain + bias))
 
 

@@ -22,7 +22,9 @@ def timed(f, n=100, reps=5):
         e1.record(); torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1) / n * 1000)
     return min(ts)
-ws = torch.empty((64 << 20,), dtype=torch.uint8, device=dev)
+ws = torch.empty((512 << 20,), dtype=torch.uint8, device=dev)
+ws[:4096].zero_()          # MM_WS_TICKETS_ZEROED (flags = 4 below): the in-kernel split-K counts arrivals there
+FLAGS = 4
 lib.mm_matmul_describe.restype = ctypes.c_char_p
 tag = " ".join(f"{k}={v}" for k, v in os.environ.items() if k.startswith("MICROMIX_"))
 print(f"# {tag or 'default'}")
@@ -37,7 +39,7 @@ for name, N, K, split in CASES:
         pp = lambda t: t.data_ptr() if t.numel() else None
         st = torch.cuda.current_stream().cuda_stream
         ptrs = [pp(t) for t in (a[0], b[0], a[1], b[1], a[2], b[2], a[3], b[3], a[4], b[4], a[5], b[5])]
-        t = timed(lambda: lib.mm_matmul_ws(*ptrs, M, N, *split, 1, 0, None, out.data_ptr(), ws.data_ptr(), ws.numel(), st))
+        t = timed(lambda: lib.mm_matmul_ws(*ptrs, M, N, *split, 1, FLAGS, None, out.data_ptr(), ws.data_ptr(), ws.numel(), st))
         wbytes = N * K // 2 + N * K // 32
-        d = lib.mm_matmul_describe(M, N, *split, 1, 0, ws.numel()).decode()
+        d = lib.mm_matmul_describe(M, N, *split, 1, FLAGS, ws.numel()).decode()
         print(f"{name:8s} N={N:5d} K={K:5d} {str(split):>20s} M={M:5d} | {t:7.1f} us {2*M*N*K/t/1e6:6.0f} TF  W-stream {wbytes/t/1e6:5.2f} TB/s | {d}", flush=True)
