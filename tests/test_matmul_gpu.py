@@ -137,6 +137,54 @@ def test_reference_smoke_shape_through_qlinear(dev):
     assert float(((C.float() - D) ** 2).mean() / D.var()) < 5e-2      # MXFP4 weights: ~1e-2 expected from the fp4 grid alone
 
 
+# launches of at most 48 64x64 tiles: split-K with the reduction inside the launch (split_tile_reduce: ticket per tile, the last
+# workgroup sums the partial sums in split order).  The DEFAULT plan is asserted, so a change of the rule cannot drop the case.
+IN_KERNEL_SPLIT = [(128, 1024, 4096, (2048, 128, 1920)), (100, 520, 2048, (1024, 256, 768)), (192, 1000, 5120, (0, 0, 5120)),
+                   (65, 700, 2560, (2048, 0, 512)), (129, 1024, 4096, (4096, 0, 0))]
+
+
+@pytest.mark.parametrize("wmode", ("w4", "w"))
+@pytest.mark.parametrize("m,n,k,split", IN_KERNEL_SPLIT)
+def test_in_kernel_split_k(dev, m, n, k, split, wmode):
+    import torch
+    from micromix_amd import _lib
+    lib = _lib.load()
+    flags = _lib.MM_WS_TICKETS_ZEROED
+    need = lib.mm_matmul_workspace_bytes(m, n, *split, 1 if wmode == "w4" else 0, flags)
+    desc = lib.mm_matmul_describe(m, n, *split, 1 if wmode == "w4" else 0, flags, need).decode()
+    assert need > 0 and "in-kernel split-K" in desc, desc
+    assert lib.mm_matmul_workspace_bytes(m, n, *split, 1 if wmode == "w4" else 0, 0) == 0 or "in-kernel" not in \
+        lib.mm_matmul_describe(m, n, *split, 1 if wmode == "w4" else 0, 0, 1 << 30).decode()     # not without the caller's word on the tickets
+    rng = np.random.default_rng(m + n + k)
+    qx, qw = quantized(rng, m, n, k, split, wmode)
+    bias = torch.from_numpy(rng.standard_normal(n).astype(np.float32)).to(torch.bfloat16).to(dev)
+    for rounding in ("reference", "fused"):
+        runs = [gpu_matmul(dev, qx, qw, rounding=rounding) for _ in range(3)]
+        assert np.array_equal(runs[0], runs[1]) and np.array_equal(runs[0], runs[2])          # whichever workgroup reduces
+        check_gemm(runs[0], qx, qw, rounding, label=f"in-kernel split {m}x{n}x{k} {split} {wmode} {rounding}")
+        check_gemm(gpu_matmul(dev, qx, qw, rounding=rounding, split_k=False), qx, qw, rounding, label="unsplit twin")
+    with_bias = gpu_matmul(dev, qx, qw, bias=bias)
+    a, b = to_dev(dev, qx), to_dev(dev, qw)
+    plain = mixedgemm.matmul(a[0], b[0], a[1], b[1], a[2], b[2], a[3], b[3], a[4], b[4], a[5], b[5])
+    assert np.array_equal(with_bias, bits_from_t(plain + bias))
+    # replayed from a hipGraph: the ticket counters are back at zero after every launch
+    out = torch.empty((m, n), dtype=torch.bfloat16, device=dev)
+    args = (a[0], b[0], a[1], b[1], a[2], b[2], a[3], b[3], a[4], b[4], a[5], b[5])
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        mixedgemm.matmul(*args, out=out)
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        mixedgemm.matmul(*args, out=out)
+    for _ in range(3):
+        out.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, plain)
+
+
 def test_split_k_is_deterministic_and_keeps_bias(dev):
     import torch
     rng = np.random.default_rng(77)
