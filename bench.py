@@ -24,6 +24,12 @@ The line also carries
   * `qlinear`    : tokens/s of the full QLinearLayer.forward hot path (reorder_quantize_x + matmul);
   * `cpu_baseline`: the CPU port of QLinearLayer.forward (oracle quantizer + dequantise + fp32 torch.matmul with the reference's
                    rounding order; the reference has no CPU path) timed on this host at M in {1, 128, 2048}.
+  * `published_config`: the reference's only published configuration (M = 32, N = K = 4096, MXFP6 x MXFP4) timed here;
+  * `quantizers`  : rmsnorm_quantize_x / activate_quantize_x / reorder_quantize_x kernel times against the 8 TB/s HBM peak;
+  * `power`       : package power / cap / shader clock sampled with rocm-smi DURING the settle phase (the 4096^3 GEMM runs at the
+                   1400 W cap: its time is set by energy).
+`value` is always the K stream launches' figure (the same launch mode `roofline.kernel_us` is measured in); the hipGraph replay of
+the same K launches is reported beside it as `graph_launch_ms_per_step`.
 With --gpus N > 1 (one process per GPU, RCCL): the north-star tensor-parallel path -- each rank holds a 128-aligned K-shard of
 every reordered segment (weights AND activation columns), computes a partial [M, N] product and the partials are summed with
 one RCCL all-reduce on the bf16 output.  Total work is fixed ("scaling": "strong"); `value` is 2*M*N*K*steps / max-over-ranks
@@ -50,7 +56,12 @@ PEAK_TFLOPS_FP4 = 10066.0     # fp6 / fp4 operands: 4096 flop/clk/SIMD
 SETTLE_S = 1.5
 # mixed splits of SURVEY.md section 8d (name, M, N, K, split)
 MIXED = [("q_o_2048_128_1920", 4096, 4096, 4096, (2048, 128, 1920)), ("q_o_3072_896_128", 4096, 4096, 4096, (3072, 896, 128)),
-         ("q_o_all_fp4", 4096, 4096, 4096, (4096, 0, 0)), ("down_12288_1024_1024", 4096, 4096, 14336, (12288, 1024, 1024))]
+         ("q_o_all_fp4", 4096, 4096, 4096, (4096, 0, 0)), ("down_12288_1024_1024", 4096, 4096, 14336, (12288, 1024, 1024)),
+         ("gate_up_0_0_4096", 4096, 14336, 4096, (0, 0, 4096)), ("gate_up_3072_896_128", 4096, 14336, 4096, (3072, 896, 128))]
+# the one configuration the reference publishes a number for (mgemm/README.md:34-46, formula mgemm/benchmark/mxf4f6f8_bench.cu:165-167):
+# gemm_host_tn, M = 32, N = K = 4096, MXFP6(E3M2) x MXFP4, 0.19270399 ms = 5.5720 TFLOPs on an RTX 5090 -- context, not a same-node comparison
+PUBLISHED = {"M": 32, "N": 4096, "K": 4096, "split": (0, 4096, 0), "reference_ms": 0.19270399, "reference_tflops": 5.5720,
+             "reference_hardware": "RTX 5090", "source": "mgemm/README.md:34-46"}
 
 
 def roofline_time_s(m, n, split):
@@ -113,6 +124,34 @@ def cpu_baseline(x, w, idx, budget_s=18.0):
             "sample": f"QLinearLayer.forward port at M in (1, 128, 2048) of the {M} token rows, full N=K=4096: oracle quantize-x + "
                       f"dequantise + fp32 torch.matmul + bf16 rounding per segment, median of >=3 repeats, {spent:.1f} s of CPU time; "
                       "`value` is the M=2048 figure"}
+
+
+def sample_power(out, delay_s=0.6):
+    """rocm-smi in a CHILD process (this process never execs), `delay_s` after the call: package power, cap and clocks while
+    the caller keeps the GPU busy.  Fills `out` (a dict); silent when rocm-smi is absent."""
+    import subprocess
+    import threading
+
+    def run():
+        try:
+            time.sleep(delay_s)
+            txt = subprocess.run(["rocm-smi", "--showpower", "--showmaxpower", "--showclocks", "--json"], capture_output=True,
+                                 text=True, timeout=20).stdout
+            card = next(iter(json.loads(txt[txt.index("{"):]).values()))
+            for k, v in card.items():
+                kl = k.lower()
+                if "max graphics package power" in kl:
+                    out["cap_w"] = float(v)
+                elif "package power" in kl:
+                    out["package_w"] = float(v)
+                elif kl.startswith("sclk clock speed"):
+                    out["sclk_mhz"] = float(str(v).strip("()Mhz ").split("Mhz")[0])
+        except Exception as e:                      # telemetry only: never fail the benchmark
+            out["error"] = str(e)[:80]
+
+    t = threading.Thread(target=run, daemon=True)
+    t.start()
+    return t
 
 
 def load_traffic():
@@ -217,9 +256,9 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    # The K timed steps are issued as ONE hipGraph holding K GEMM launches (single GPU): consecutive launches from a stream
-    # leave a ~4 us gap at every kernel boundary, a graph about half of that (tools/graph_gap.py: 57-60 vs 54-56 us per step).
-    # Capture happens here, outside the timed region; MICROMIX_BENCH_GRAPH=0 times plain stream launches instead.
+    # The same K steps are also captured as ONE hipGraph holding K GEMM launches (single GPU) and replayed after the timed
+    # region as an auxiliary figure (consecutive launches from a stream leave a ~4 us gap at every kernel boundary, a graph about
+    # half of that on most boxes: tools/graph_gap.py).  Capture happens here, outside any timed region; MICROMIX_BENCH_GRAPH=0 skips it.
     graph = None
     if world == 1 and os.environ.get("MICROMIX_BENCH_GRAPH", "1") != "0":
         try:
@@ -236,33 +275,31 @@ def main():
         except Exception as e:          # fall back to stream launches
             print(f"[bench] hipGraph capture failed ({e}); timing stream launches", file=sys.stderr)
             graph = None
-    extra_launch = "one hipGraph of K GEMM launches" if graph is not None else "K stream launches"
+    power = {}
+    sampler = sample_power(power) if rank == 0 and world == 1 else None
     prewarm_s = settle(step)
-    # timed region: exactly K steps, nothing else
+    if sampler is not None:
+        sampler.join(timeout=25)
+        settle(step, 0.3)           # (rocm-smi may have outlasted the settle phase)
+    # timed region: exactly K steps as plain stream launches, nothing else
     barrier()
     t0 = time.perf_counter()
-    if graph is not None:
-        graph.replay()
-    else:
-        for _ in range(args.steps):
-            step()
+    for _ in range(args.steps):
+        step()
     barrier()
     dt = time.perf_counter() - t0
-    # the same K steps once more as plain stream launches, timed the same way.  Which of the two launch modes is faster differs
-    # between devices of the pool (graph 55.6 vs stream 53.9 us on one box, 54 vs 57-60 on another), so the faster pass is
-    # `value` and the line says which; both figures are printed.
-    graph_ms = stream_ms = None
+    extra_launch = "K stream launches"
+    # the same K steps once more as ONE hipGraph replay, timed the same way (auxiliary figure: which of the two modes is
+    # faster differs between devices of the pool -- graph 55.6 vs stream 53.9 us on one box, 54 vs 57-60 on another -- so
+    # `value` is pinned to the stream launches, the mode roofline.kernel_us is measured in)
+    graph_ms = None
+    stream_ms = dt * 1e3 / args.steps
     if graph is not None:
-        graph_ms = dt * 1e3 / args.steps
         barrier()
         t1 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
+        graph.replay()
         barrier()
-        dt_stream = time.perf_counter() - t1
-        stream_ms = dt_stream * 1e3 / args.steps
-        if dt_stream < dt:
-            dt, extra_launch = dt_stream, "K stream launches (faster than the hipGraph of K launches on this device)"
+        graph_ms = (time.perf_counter() - t1) * 1e3 / args.steps
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -283,9 +320,11 @@ def main():
                    "M": M, "N": N, "K": K, "split": list(SPLIT), "weight_mode": "w4", "parallelism": parallelism,
                    "launch": extra_launch},
     }
-    if stream_ms is not None:
+    if graph_ms is not None:
         result["graph_launch_ms_per_step"] = round(graph_ms, 5)
-        result["stream_launch_ms_per_step"] = round(stream_ms, 5)
+    result["stream_launch_ms_per_step"] = round(stream_ms, 5)
+    if power:
+        result["power"] = dict(power, sampled="rocm-smi during the settle phase (back-to-back GEMM launches)")
 
     if rank == 0 and world == 1:
         traffic = load_traffic()
@@ -318,11 +357,21 @@ def main():
             om = out if (mm_, nn_) == (M, N) else torch.empty((mm_, nn_), dtype=torch.bfloat16, device=dev)
             f = lambda: mm(am, bm, om)
             settle(f, 0.4)
-            us = kernel_us(f, args.steps)
+            desc = lib.mm_matmul_describe(mm_, nn_, *split, 1, 0, 0).decode()
+            if " + " in desc:       # two launches (tail balancing): events around K back-to-back calls, launch gaps included
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(args.steps):
+                    f()
+                e1.record()
+                torch.cuda.synchronize()
+                us, how = e0.elapsed_time(e1) * 1e3 / args.steps, "events around K back-to-back calls (two launches per call, gaps included)"
+            else:
+                us, how = kernel_us(f, args.steps), "HIP events attached to the dispatch"
             tstar = roofline_time_s(mm_, nn_, split) * 1e6
-            mixed[name] = {"M": mm_, "N": nn_, "K": kk_, "split": list(split), "kernel_us": round(us, 2),
+            mixed[name] = {"M": mm_, "N": nn_, "K": kk_, "split": list(split), "kernel_us": round(us, 2), "kernel_us_source": how,
                            "tflops": round(2.0 * mm_ * nn_ * kk_ / us / 1e6, 1), "roofline_us": round(tstar, 2),
-                           "frac": round(tstar / us, 4), "kernel": lib.mm_matmul_describe(mm_, nn_, *split, 1, 0, 0).decode()}
+                           "frac": round(tstar / us, 4), "kernel": desc}
             del am, bm
         result["mixed"] = mixed
 
@@ -360,6 +409,70 @@ def main():
         result["decode"] = dec
         del bf
         result["few_tiles"] = few
+
+        # ---- the reference's one published configuration: gemm_host_tn, M = 32, N = K = 4096, MXFP6 x MXFP4 ----
+        pm, pn, pk, psplit = PUBLISHED["M"], PUBLISHED["N"], PUBLISHED["K"], PUBLISHED["split"]
+        bp = mixedgemm.reorder_quantize_w4(w, idx, *psplit)
+        ap = mixedgemm.reorder_quantize_x(x[:pm].contiguous(), idx, *psplit)
+        op = torch.empty((pm, pn), dtype=torch.bfloat16, device=dev)
+        ptr = lambda t: t.data_ptr() if t.numel() else None
+        sptr = torch.cuda.current_stream().cuda_stream
+        pargs = [ptr(t) for t in (ap[0], bp[0], ap[1], bp[1], ap[2], bp[2], ap[3], bp[3], ap[4], bp[4], ap[5], bp[5])]
+        fp = lambda: lib.mm_matmul(*pargs, pm, pn, *psplit, 1, 0, None, op.data_ptr(), sptr)
+        assert fp() == 0
+        settle(fp, 0.2)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(200):
+            fp()
+        e1.record()
+        torch.cuda.synchronize()
+        t_pub = e0.elapsed_time(e1) * 1e-3 / 200
+        result["published_config"] = {
+            "M": pm, "N": pn, "K": pk, "split": list(psplit), "formats": "MXFP6(E3M2) x MXFP4, w4 weights",
+            "us_per_launch": round(t_pub * 1e6, 2), "tflops": round(2.0 * pm * pn * pk / t_pub / 1e12, 2),
+            "kernel": lib.mm_matmul_describe(pm, pn, *psplit, 1, 0, 0).decode() if pm > 64 else "mm_matmul weight-streaming kernel (M <= 64)",
+            "timing": "200 back-to-back launches through the C ABI between two events on the launch stream (launch gaps included)",
+            "reference": {k: PUBLISHED[k] for k in ("reference_ms", "reference_tflops", "reference_hardware", "source")},
+            "note": "context only: the reference's figure is its hand-written CuTe kernel on other hardware; same shape, formats and TFLOPS formula",
+        }
+        del bp, ap
+
+        # ---- the other quantizers of the path (section 8f): kernel time and algorithmic bytes against 8 TB/s ----
+        def timed_direct(fn, reps=100):
+            assert fn() == 0
+            for _ in range(10):
+                fn()
+            torch.cuda.synchronize()
+            a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a0.record()
+            for _ in range(reps):
+                fn()
+            a1.record()
+            torch.cuda.synchronize()
+            return a0.elapsed_time(a1) * 1e-3 / reps
+        quant = {}
+        qsplit = (2048, 128, 1920)
+        qo2 = mixedgemm.reorder_quantize_x(x, idx, *qsplit)
+        out_b = M * (qsplit[0] // 2 + qsplit[1] * 3 // 4 + qsplit[2]) + M * K // 32
+        normw = torch.ones((K,), dtype=torch.bfloat16, device=dev)
+        t_rms = timed_direct(lambda: lib.mm_rmsnorm_quantize(x.data_ptr(), normw.data_ptr(), 1e-5, M, K, idx.data_ptr(), *qsplit, 0,
+                                                             *[ptr(t) for t in qo2], sptr))
+        t_reo = timed_direct(lambda: lib.mm_reorder_quantize(x.data_ptr(), M, K, idx.data_ptr(), *qsplit, 0, *[ptr(t) for t in qo2], sptr))
+        for name, t, byts in (("rmsnorm_quantize_x", t_rms, 2 * M * K + out_b + 4 * K), ("reorder_quantize_x", t_reo, 2 * M * K + out_b + 2 * K)):
+            quant[name] = {"rows": M, "K": K, "split": list(qsplit), "kernel_us": round(t * 1e6, 2), "GBps": round(byts / t / 1e9, 1),
+                           "frac_of_8TBps": round(byts / t / 8e12, 4)}
+        inter, asplit = 14336, (12288, 1024, 1024)
+        ga = torch.randn((M, inter), device=dev, dtype=torch.float32).to(torch.bfloat16)
+        gb = torch.randn((M, inter), device=dev, dtype=torch.float32).to(torch.bfloat16)
+        qa = mixedgemm.activate_quantize_x(ga, gb, *asplit)
+        t_act = timed_direct(lambda: lib.mm_activate_quantize(ga.data_ptr(), gb.data_ptr(), M, *asplit, *[ptr(t) for t in qa], sptr), 50)
+        act_b = 2 * 2 * M * inter + M * (asplit[0] // 2 + asplit[1] * 3 // 4 + asplit[2]) + M * inter // 32
+        quant["activate_quantize_x"] = {"rows": M, "K": inter, "split": list(asplit), "kernel_us": round(t_act * 1e6, 2),
+                                        "GBps": round(act_b / t_act / 1e9, 1), "frac_of_8TBps": round(act_b / t_act / 8e12, 4)}
+        quant["timing"] = "back-to-back direct C-ABI launches between two events on the launch stream"
+        result["quantizers"] = quant
+        del ga, gb, qa, qo2
 
         # ---- the full QLinearLayer.forward hot path, and the "w" weight mode ----
         def timed(fn):
