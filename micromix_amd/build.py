@@ -55,20 +55,60 @@ def needs_build() -> bool:
     return False
 
 
+GUARDED = "mx_gemm256.hip"     # its 8-wave tile kernels keep their accumulators in asm-owned AGPRs: tools/check_acc_regs.py
+
+
+def verify_acc_regs(objdir: str = OBJDIR) -> int:
+    """The assembly hipcc generated for mx_gemm256.hip (kept by -save-temps=obj) must not touch an accumulator AGPR outside
+    the inline asm; raises RuntimeError otherwise.  Part of every build of that file, whatever its flags."""
+    sys.path.insert(0, os.path.join(os.path.dirname(PKG), "tools"))
+    try:
+        import check_acc_regs
+    finally:
+        sys.path.pop(0)
+    asm = [f for f in os.listdir(objdir) if f.startswith("mx_gemm256") and f.endswith(".s") and "gfx950" in f]
+    if not asm:
+        raise RuntimeError("no device assembly of mx_gemm256.hip found (was it compiled with -save-temps=obj?)")
+    return check_acc_regs.verify(open(os.path.join(objdir, asm[0])).read())
+
+
+def _flags_changed(flags) -> bool:
+    """objects in OBJDIR were compiled with other flags (an -D ablation build, --keep-temps): they must not be reused"""
+    stamp = os.path.join(OBJDIR, "flags.txt")
+    want = " ".join(flags)
+    if os.path.exists(stamp) and open(stamp).read() == want:
+        return False
+    os.makedirs(OBJDIR, exist_ok=True)
+    with open(stamp, "w") as f:
+        f.write(want)
+    return True
+
+
 def build(force: bool = False, keep_temps: bool = False, verbose: bool = True, extra_flags=()) -> str:
+    flags = [*FLAGS, *extra_flags] + (["-save-temps=obj"] if keep_temps else [])
+    if _flags_changed(flags):
+        force = True
     if not force and not needs_build():
         return LIB
     os.makedirs(OBJDIR, exist_ok=True)
     cc, ht = hipcc(), _newest_header()
-    flags = [*FLAGS, *extra_flags] + (["-save-temps=obj"] if keep_temps else [])
 
     def compile_one(src):
         s, obj = os.path.join(CSRC, src), os.path.join(OBJDIR, src.replace(".hip", ".o"))
         if force or _stale(obj, ht, s):
-            cmd = [cc, *flags, "-c", s, "-o", obj]
+            guarded = src == GUARDED and "-save-temps=obj" not in flags
+            cmd = [cc, *flags, *(["-save-temps=obj"] if guarded else []), "-c", s, "-o", obj]
             if verbose:
                 print("[micromix_amd.build]", " ".join(cmd), flush=True)
             subprocess.check_call(cmd, cwd=OBJDIR)
+            if src == GUARDED:
+                n = verify_acc_regs(OBJDIR)       # a violation fails the build: the library would compute wrong GEMMs
+                if verbose:
+                    print(f"[micromix_amd.build] accumulator-register guard: {n} tile kernels clean", flush=True)
+                if guarded:                       # the temporaries were kept for the guard only
+                    for f in os.listdir(OBJDIR):
+                        if f.startswith("mx_gemm256") and f != "mx_gemm256.o":
+                            os.remove(os.path.join(OBJDIR, f))
         return obj
 
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:

@@ -204,7 +204,7 @@ static int plan_splits(int M, int N, const int K[3], bool w4, bool force, int fi
         total += n[i];
         nonempty += n[i] > 0;
     }
-    int cap = 256 / tiles;          // one wave of workgroups on the 256 CUs
+    int cap = device_cus() / tiles; // one wave of workgroups on the CUs
     cap = cap > 16 ? 16 : cap;
     cap = cap > total / 2 ? total / 2 : cap;  // at least two slabs per split on average
     if (cap < 2 || cap < nonempty) return 0;
@@ -220,7 +220,8 @@ static int plan_splits(int M, int N, const int K[3], bool w4, bool force, int fi
         // split at M <= 384, unsplit 64 x 128 tiles at M = 512; k/v and q/o at K = 4096: never split).
         const int t32n = ((M + 63) / 64) * ((N + 63) / 64), t32 = ((M + 63) / 64) * ((N + 127) / 128);
         const int t64 = ((M + 127) / 128) * ((N + 127) / 128);
-        const bool g32n_fits = t32n <= 256, g32_fits = !g32n_fits && t32 <= 256 && 2 * t64 <= 256;   // as plan_tiles
+        const int cus = device_cus();
+        const bool g32n_fits = t32n <= cus, g32_fits = !g32n_fits && t32 <= cus && 2 * t64 <= cus;   // as plan_tiles
         const float unsplit = (g32n_fits ? 0.32f : g32_fits ? 0.36f : 0.5f) * total, margin = g32_fits ? 0.95f : 0.85f;
         const float split = 0.7f * total / S + 0.064f * tiles * S + 5.0f;
         if (S < 2 || split > margin * unsplit) return 0;

@@ -13,11 +13,7 @@ typedef unsigned u6 __attribute__((ext_vector_type(6)));
 // e == -127 (every element of the block is below FMAX * 2^-127): 2^127 times the value, integer encoder.
 // Inlined on purpose: as a __noinline__ call it cost 40 % of the kernel's time (15.3 vs 10.9 us at 4096 x 4096) although
 // it is practically never taken -- the call site pins the caller's registers.
-#if defined(MM_QDBG) && (MM_QDBG & 1)
-#define MM_TINY_INLINE __noinline__
-#else
 #define MM_TINY_INLINE __forceinline__
-#endif
 // two fp32 -> packed bf16 pair {lo, hi}, round to nearest even (v_cvt_pk_bf16_f32)
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
     uint32_t r = 0;

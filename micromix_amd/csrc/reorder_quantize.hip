@@ -16,9 +16,6 @@
 //  * all scale arithmetic is integer/exponent arithmetic (no log2/ceil/ldexp/divide); the element conversion is
 //    one hardware MX-converter instruction per 2 (fp4/fp8) or 32 (fp6) elements.
 #include "mx_common.h"
-#ifndef MM_QDBG
-#define MM_QDBG 0  // kernel-developer A/B switches: 1 = tiny-block path out of line, 2 = byte SF stores, 4 = fixed 2048-block grid
-#endif
 #include "mx_group_convert.h"
 #include "mx_kernels.h"
 
@@ -104,15 +101,11 @@ __device__ __forceinline__ void reorder_quantize_body(const uint16_t *__restrict
             }
             // the 4 block scales of one row and one 128-column slab are 4 consecutive bytes of the SF layout: gather them
             // from the lane quad (segment widths are multiples of 128, so a quad never straddles segments) and store a dword
-#if (MM_QDBG & 2)
-            sf[sf_offset(r, j, kseg)] = (uint8_t)byte;
-#else
             const uint32_t b1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)byte, 0x55, 0xF, 0xF, false);
             const uint32_t b2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)byte, 0xAA, 0xF, 0xF, false);
             const uint32_t b3 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)byte, 0xFF, 0xF, 0xF, false);
             if ((g & 3) == 0)
                 *reinterpret_cast<uint32_t *>(sf + sf_offset(r, j, kseg)) = byte | (b1 << 8) | (b2 << 16) | (b3 << 24);
-#endif
         }
         __syncthreads();
         if (rn < rows) {

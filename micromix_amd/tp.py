@@ -212,6 +212,12 @@ class ColumnParallelLinear:
         self.index = reorder_index.to(torch.int16).contiguous()
         self.empty = features.numel() == 0
         self.gather_output = gather_output
+        if gather_output and world > 1:
+            # all_gather needs the same width on every rank (RCCL hangs or corrupts on mismatched shapes) and no empty shard
+            if features is not None and self.features.numel() * world != self.N:
+                raise ValueError(f"gather_output=True needs equal, non-empty shards on every rank: rank {rank} holds "
+                                 f"{self.features.numel()} of {self.N} features for world size {world} (shards are 128-feature "
+                                 "granules: N must be a multiple of 128 * world, or pass equal `features` slices)")
         self.bias = bias[features.to(bias.device)] if bias is not None else None
         if not self.empty:
             self.packed_w = self.ops.quantize_w4(w[features.to(w.device)].contiguous(), self.index, p4, p6, p8)
@@ -220,6 +226,8 @@ class ColumnParallelLinear:
         return self.ops.quantize_x(x, self.index, *self.split)
 
     def matmul(self, qx):
+        if self.empty:      # a rank without features (N < 128 * world): an [M, 0] slice, so that callers need no special case
+            return torch.empty((qx[0].shape[0], 0), dtype=torch.bfloat16, device=getattr(qx[0], "device", None))
         y = self.ops.matmul(qx, self.packed_w, rounding="reference")
         if self.bias is not None:
             y = y + self.bias

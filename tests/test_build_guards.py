@@ -23,9 +23,16 @@ def test_compiler_leaves_the_accumulator_agprs_alone():
                         "--cuda-device-only", os.path.join(ROOT, "micromix_amd", "csrc", "mx_gemm256.hip"), "-o", out],
                        check=True, cwd=tmp, stderr=subprocess.DEVNULL)
         text = open(out).read()
-    assert text.count(".end_amdhsa_kernel") >= 10            # the parser below must have kernels to look at
-    bad = check_acc_regs.check(text)
+    bad, examined = check_acc_regs.check_counted(text)
+    assert len(examined) >= check_acc_regs.EXPECTED_KERNELS, examined     # the regex must have matched every tile kernel
     assert not bad, "\n".join(f"{s}: {c}" for s, c in bad[:10])
+
+
+def test_the_build_runs_the_guard():
+    """python -m micromix_amd.build keeps the assembly of mx_gemm256.hip and fails on a violation (micromix_amd/build.py)"""
+    from micromix_amd import build
+    import inspect
+    assert "verify_acc_regs" in inspect.getsource(build.build)
 
 
 def test_the_guard_itself_detects_a_violation():

@@ -216,3 +216,22 @@ def test_shard_positions_partition_the_intermediate_features():
             plan = tp.plan_k_shards(*split, world)
             pos = torch.cat([tp.shard_positions(*split, plan[r]) for r in range(world)])
             assert torch.equal(torch.sort(pos).values, torch.arange(sum(split)))
+
+
+def test_column_parallel_gather_needs_equal_shards():
+    """all_gather with ranks of different widths hangs or corrupts on RCCL: the constructor refuses such a layout, and a rank
+    without features returns an [M, 0] slice instead of failing while the other ranks wait in a collective"""
+    tb = lambda bits: torch.from_numpy(bits.view(np.int16).copy()).view(torch.bfloat16)
+    k, split = 256, (128, 0, 128)
+    idx = torch.from_numpy(np.random.default_rng(0).permutation(k).astype(np.int16))
+    w = tb(lcg.bf16_normalish(3, (384, k), exp_center=121))                # 3 granules of 128 features over 2 ranks: 256 + 128
+    with pytest.raises(ValueError, match="equal, non-empty shards"):
+        tp.ColumnParallelLinear(w, idx, *split, rank=0, world=2, ops=OracleOps, gather_output=True)
+    with pytest.raises(ValueError, match="equal, non-empty shards"):
+        tp.ColumnParallelLinear(w, idx, *split, rank=1, world=2, ops=OracleOps, gather_output=True)
+    tp.ColumnParallelLinear(w[:256], idx, *split, rank=1, world=2, ops=OracleOps, gather_output=True)      # 128 + 128: fine
+    lone = tp.ColumnParallelLinear(w[:128], idx, *split, rank=1, world=2, ops=OracleOps)                   # rank 1 gets nothing
+    assert lone.empty
+    x = tb(lcg.bf16_normalish(4, (5, k)))
+    y = lone.matmul(lone.quantize_x(x))
+    assert tuple(y.shape) == (5, 0) and y.dtype == torch.bfloat16

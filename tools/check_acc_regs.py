@@ -19,12 +19,24 @@ def agprs(line):
     return out
 
 
+EXPECTED_KERNELS = 14   # g256: 2 + 2 grouped; g128: 2 + 2 split-K + 2 grouped; g64: 2 + 2 grouped
+
+
 def check(asm_text):
-    bad = []
+    """violations only (see check_counted)"""
+    return check_counted(asm_text)[0]
+
+
+def check_counted(asm_text):
+    """(violations, symbols of the kernels with asm-owned accumulators that were examined).  A caller must also require
+    len(examined) >= EXPECTED_KERNELS: a name-mangling change would otherwise make the check pass with nothing examined."""
+    bad, examined = [], []
     for m in re.finditer(r"^(_ZN2mm\d(g(?:256|128|64|32n|32))(?:17|25)mx_gemm256_(?:grouped_)?kernel\w*):[^\n]*\n(.*?)\.end_amdhsa_kernel",
                          asm_text, re.S | re.M):
         sym, ns, body = m.group(1), m.group(2), m.group(3)
         n = NACC[ns]
+        if n:
+            examined.append(sym)
         for line in body.split("\n"):
             code = line.split(";")[0]
             if not code.strip() or code.strip().startswith("."):
@@ -37,7 +49,19 @@ def check(asm_text):
             if own and not re.search(r"\ba\d+\b", code):
                 continue
             bad.append((sym, code.strip()))
-    return bad
+    return bad, examined
+
+
+def verify(asm_text):
+    """raises RuntimeError on a violation or when fewer kernels than expected were found; returns the number examined"""
+    bad, examined = check_counted(asm_text)
+    if bad:
+        raise RuntimeError("hipcc allocated a temporary in an accumulator AGPR of a tile kernel (results would be corrupted):\n" +
+                           "\n".join(f"  {s}: {c}" for s, c in bad[:10]))
+    if len(examined) < EXPECTED_KERNELS:
+        raise RuntimeError(f"accumulator-register check found {len(examined)} tile kernels, expected >= {EXPECTED_KERNELS} "
+                           "(kernel names changed? update tools/check_acc_regs.py)")
+    return len(examined)
 
 
 def main():
@@ -46,11 +70,11 @@ def main():
         cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-fno-gpu-rdc", "-S", "--cuda-device-only",
                src, "-o", os.path.join(tmp, "k.s")] + sys.argv[1:]
         subprocess.run(cmd, check=True, cwd=tmp)
-        bad = check(open(os.path.join(tmp, "k.s")).read())
+        bad, examined = check_counted(open(os.path.join(tmp, "k.s")).read())
     for sym, code in bad[:20]:
         print(f"accumulator register used by the compiler in {sym}: {code}")
-    print(f"{len(bad)} violation(s)")
-    return 1 if bad else 0
+    print(f"{len(bad)} violation(s) in {len(examined)} tile kernels with asm-owned accumulators (expected >= {EXPECTED_KERNELS})")
+    return 1 if bad or len(examined) < EXPECTED_KERNELS else 0
 
 
 if __name__ == "__main__":
