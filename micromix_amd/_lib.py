@@ -27,7 +27,7 @@ DIAG_EXPORTS = ("mm_diag_mfma", "mm_diag_hw_convert", "mm_diag_mfma_rate", "mm_d
 MM_OK, MM_ERR_BAD_SPLIT, MM_ERR_BAD_ARG, MM_ERR_LAUNCH, MM_ERR_UNSUPPORTED, MM_ERR_NO_DEVICE = range(6)
 MM_QUANT_MIXED, MM_QUANT_W4 = 0, 1
 MM_W_MATCH, MM_W_FP4 = 0, 1
-MM_ROUND_PER_SEGMENT, MM_ROUND_ONCE, MM_SPLIT_K_ALWAYS, MM_WS_TICKETS_ZEROED = 0, 1, 2, 4
+MM_ROUND_PER_SEGMENT, MM_ROUND_ONCE, MM_SPLIT_K_ALWAYS, MM_WS_TICKETS_ZEROED, MM_OUT_F32 = 0, 1, 2, 4, 8
 MM_WS_TICKET_BYTES = 4096
 MM_RMS_REFERENCE, MM_RMS_NO_INTEGER_ROUND = 0, 1
 

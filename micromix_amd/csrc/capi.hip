@@ -162,11 +162,13 @@ int mm_matmul_ws(const uint8_t *AN, const uint8_t *BN, const uint8_t *AS, const 
     if (wmode != MM_W_MATCH && wmode != MM_W_FP4) return MM_ERR_BAD_ARG;
     if (M == 0 || N == 0) return MM_OK;
     if (!D_bf16) return MM_ERR_BAD_ARG;
+    const bool out_f32 = (flags & MM_OUT_F32) != 0;
+    if (out_f32 && (!(flags & MM_ROUND_ONCE) || bias_bf16)) return MM_ERR_BAD_ARG;   // fp32 partial sums: no chain rounding, no bias
     if ((KN && (!AN || !BN || !SFAN || !SFBN)) || (KS && (!AS || !BS || !SFAS || !SFBS)) ||
         (KO && (!AO || !BO || !SFAO || !SFBO)))
         return MM_ERR_BAD_ARG;
     if (KN + KS + KO == 0) {  // reference: C = zeros, no segment runs (gemm.cu:48-50)
-        hipError_t e = hipMemsetAsync(D_bf16, 0, (size_t)M * N * 2, (hipStream_t)stream);
+        hipError_t e = hipMemsetAsync(D_bf16, 0, (size_t)M * N * (out_f32 ? 4 : 2), (hipStream_t)stream);
         return e == hipSuccess ? MM_OK : fail_hip(e, "mm_matmul(memset)");
     }
     mm::GemmArgs a;
@@ -184,6 +186,7 @@ int mm_matmul_ws(const uint8_t *AN, const uint8_t *BN, const uint8_t *AS, const 
     a.round_per_segment = (flags & MM_ROUND_ONCE) ? 0 : 1;
     a.bias = (const uint16_t *)bias_bf16;
     a.D = (uint16_t *)D_bf16;
+    a.out_f32 = out_f32 ? 1 : 0;
     a.clock_out = g_clock_buf;
     a.ev_start = g_ev_start;
     a.ev_stop = g_ev_stop;
@@ -267,6 +270,7 @@ int mm_matmul_grouped(const mm_group *groups, int ngroups, int N, int KN, int KS
         a.round_per_segment = (flags & MM_ROUND_ONCE) ? 0 : 1;
         a.bias = (const uint16_t *)g.bias_bf16;
         a.D = (uint16_t *)g.D;
+        a.out_f32 = 0;
         a.clock_out = nullptr;
         a.ev_start = a.ev_stop = nullptr;
         a.ws = nullptr; a.ws_bytes = 0; a.splits = 0; a.force_split = 0; a.n_tile0 = a.n_tiles = 0;

@@ -166,6 +166,13 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(GemmArgs a, int tile
     const int m = (tile / tiles_n) * g128::BM + wm * 32 + (r & 3) + 8 * ((r >> 2) & 3) + 4 * (lane >> 5);
     const int n = (tile % tiles_n) * g128::BN + wn * 128 + (r >> 4) * 32 + (lane & 31);   // lane & 3 == 0
     if (m >= a.M) return;
+    if (a.out_f32) {     // MM_OUT_F32: the fp32 sums themselves
+        float *d32 = reinterpret_cast<float *>(a.D) + (size_t)m * a.N + n;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (n + i < a.N) d32[i] = run[i];
+        return;
+    }
     uint32_t b[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {

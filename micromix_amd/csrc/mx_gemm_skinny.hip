@@ -178,6 +178,10 @@ __device__ __forceinline__ void skinny_body(const GemmArgs &a) {
         const int m = t * 32 + (i & 3) + 8 * (i >> 2) + 4 * (l >> 5);
         const int n = n0 + (l & 31);
         if (m < a.M && n < a.N) {
+            if (a.out_f32) {     // MM_OUT_F32: the fp32 sum itself
+                reinterpret_cast<float *>(a.D)[(size_t)m * a.N + n] = run[j];
+                continue;
+            }
             uint32_t b = f32_to_bf16_bits(run[j]);
             if (a.bias != nullptr) b = f32_to_bf16_bits(bf16_bits_to_f32(b) + bf16_bits_to_f32(a.bias[n]));
             a.D[(size_t)m * a.N + n] = (uint16_t)b;
@@ -299,6 +303,10 @@ __device__ __forceinline__ void skinny16_body(const GemmArgs &a) {
         for (int j = 0; j < T16; ++j) {
             const int m = 16 * j + 4 * (l >> 4) + i;            // D[4 * (lane >> 4) + register][lane & 15] per token tile
             if (m < a.M && n < a.N) {
+                if (a.out_f32) {     // MM_OUT_F32: the fp32 sum itself
+                    reinterpret_cast<float *>(a.D)[(size_t)m * a.N + n] = run[j];
+                    continue;
+                }
                 uint32_t b = f32_to_bf16_bits(run[j]);
                 if (a.bias != nullptr) b = f32_to_bf16_bits(bf16_bits_to_f32(b) + bf16_bits_to_f32(a.bias[n]));
                 a.D[(size_t)m * a.N + n] = (uint16_t)b;

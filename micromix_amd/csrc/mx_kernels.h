@@ -50,7 +50,8 @@ struct GemmArgs {
     int sfw_row_tiles;
     int round_per_segment;
     const uint16_t *bias;   // optional [N] bf16
-    uint16_t *D;            // [M, N] bf16
+    uint16_t *D;            // [M, N] bf16 (out_f32 = 0)
+    int out_f32;            // MM_OUT_F32: D is [M, N] fp32 instead -- the accumulator as it is, no rounding (tensor-parallel partial sums)
     float *ws;              // split-K workspace (NULL: never split), see mm_matmul_ws
     size_t ws_bytes;
     int force_split;        // MM_SPLIT_K_ALWAYS

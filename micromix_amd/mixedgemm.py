@@ -160,13 +160,14 @@ def split_workspace(dev, nbytes):
 
 
 def matmul(AN, BN, AS, BS, AO, BO, SFAN, SFBN, SFAS, SFBS, SFAO, SFBO, *, bias=None, rounding="reference", out=None,
-           split_k=True):
+           split_k=True, out_dtype=torch.bfloat16):
     """bindings.cpp:50-102.  Returns a new [M, N] bf16 tensor.
 
     Keyword-only extras (not in the reference): `bias` [N] bf16 fused into the epilogue, `rounding` "reference" (bf16 after
     each segment, as the chained reference kernels) or "fused", `out` to write into an existing tensor, `split_k=False`
     to forbid the K-split the library uses for shapes with few output tiles (it needs a scratch tensor; "force" splits
-    wherever the shape allows, for tests).
+    wherever the shape allows, for tests), `out_dtype=torch.float32` for the unrounded fp32 accumulator (MM_OUT_F32: the partial
+    products of a K-sharded tensor-parallel layer; needs rounding="fused" and no bias).
 
     Shapes are derived exactly as the reference does (bindings.cpp:66-70) and the weight mode
     from `AS.size(1) == BS.size(1) and AO.size(1) == BO.size(1)` (bindings.cpp:74,87).
@@ -207,16 +208,22 @@ def matmul(AN, BN, AS, BS, AO, BO, SFAN, SFBN, SFAS, SFBS, SFAO, SFBO, *, bias=N
         flags = _lib.MM_ROUND_ONCE
     else:
         raise ValueError("rounding must be 'reference' or 'fused'")
+    if out_dtype not in (torch.bfloat16, torch.float32):
+        raise ValueError("out_dtype must be torch.bfloat16 or torch.float32")
+    if out_dtype == torch.float32:
+        if rounding != "fused" or bias is not None:
+            raise ValueError("out_dtype=torch.float32 (fp32 partial sums) needs rounding='fused' and no bias")
+        flags |= _lib.MM_OUT_F32
     if bias is not None:
         if not _ok(bias, torch.bfloat16, index):
             _check_tensor(bias, "bias", torch.bfloat16, dev)
         if bias.numel() != N:
             raise RuntimeError("bias must have N elements")
     if out is None:
-        out = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+        out = torch.empty((M, N), dtype=out_dtype, device=dev)
     else:
-        if not _ok(out, torch.bfloat16, index):
-            _check_tensor(out, "out", torch.bfloat16, dev)
+        if not _ok(out, out_dtype, index):
+            _check_tensor(out, "out", out_dtype, dev)
         if out.dim() != 2 or out.size(0) != M or out.size(1) != N:
             raise RuntimeError("out has the wrong shape")
     # the kernels move operands in 16-byte pieces (LDS-DMA, dwordx4 loads): views at odd offsets are rejected, not mis-read

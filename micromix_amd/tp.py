@@ -97,6 +97,13 @@ class _HipOps:
         return mixedgemm.matmul(a[0], b[0], a[1], b[1], a[2], b[2], a[3], b[3], a[4], b[4], a[5], b[5], out=out, rounding=rounding)
 
     @staticmethod
+    def matmul_f32(a, b, out=None):
+        """the shard's product as the unrounded fp32 accumulator (MM_OUT_F32)"""
+        from . import mixedgemm
+        return mixedgemm.matmul(a[0], b[0], a[1], b[1], a[2], b[2], a[3], b[3], a[4], b[4], a[5], b[5], out=out, rounding="fused",
+                                out_dtype=torch.float32)
+
+    @staticmethod
     def activate_quantize(a, b, kn, ks, ko):
         from . import mixedgemm
         return mixedgemm.activate_quantize_x(a, b, kn, ks, ko)
@@ -172,9 +179,29 @@ class TPShardedLinear:
             out += self.bias
         return out
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def matmul_allreduce_f32(self, qx, m: int | None = None) -> torch.Tensor:
+        """the same reduction with FP32 partial sums: every rank's GEMM leaves its unrounded fp32 accumulator (MM_OUT_F32), the
+        all-reduce adds fp32 values and the result is rounded to bf16 ONCE -- within one bf16 ulp of the unsharded fused product
+        whatever the world size (the bf16 path accumulates up to `world` half-ulps), at twice the bytes on the wire."""
+        import torch.distributed as dist
+        if self.empty:
+            if m is None:
+                raise ValueError("an empty shard needs the row count `m`")
+            part = torch.zeros((m, self.N), dtype=torch.float32, device=self.index.device)
+        else:
+            part = self.ops.matmul_f32(qx, self.packed_w)
+        if self.world > 1:
+            dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.group)
+        out = part.to(torch.bfloat16)
+        if self.bias is not None:
+            out += self.bias
+        return out
+
+    def forward(self, x: torch.Tensor, fp32_partials: bool = False) -> torch.Tensor:
         lead = x.shape[:-1]
         x2 = x.reshape(-1, self.K).contiguous()
+        if fp32_partials:
+            return self.matmul_allreduce_f32(self.quantize_x(x2), m=x2.shape[0]).reshape(*lead, self.N)
         out = torch.empty((x2.shape[0], self.N), dtype=torch.bfloat16, device=x2.device)
         y = self.matmul_allreduce(self.quantize_x(x2), out=out)
         return y.reshape(*lead, self.N)

@@ -185,6 +185,38 @@ def test_in_kernel_split_k(dev, m, n, k, split, wmode):
         assert torch.equal(out, plain)
 
 
+# MM_OUT_F32: the unrounded fp32 accumulator as output (partial products of a K-sharded tensor-parallel layer), on every kernel
+# family: weight-streaming (16- and 32-feature), 64-row tiles (unsplit and in-kernel split), 128-row tiles, two-launch split-K,
+# 256-row tiles; ragged M and N
+F32_SHAPES = [(9, 200, 640, (256, 128, 256)), (40, 300, 512, (256, 0, 256)), (128, 1024, 4096, (2048, 128, 1920)),
+              (250, 4000, 640, (256, 128, 256)), (700, 4090, 640, (256, 128, 256)), (192, 256, 14336, (12288, 1024, 1024)),
+              (1000, 2050, 768, (256, 256, 256))]
+
+
+@pytest.mark.parametrize("wmode", ("w4", "w"))
+@pytest.mark.parametrize("m,n,k,split", F32_SHAPES)
+def test_fp32_output(dev, m, n, k, split, wmode):
+    import torch
+    rng = np.random.default_rng(m + 3 * n + k)
+    qx, qw = quantized(rng, m, n, k, split, wmode)
+    a, b = to_dev(dev, qx), to_dev(dev, qw)
+    args = (a[0], b[0], a[1], b[1], a[2], b[2], a[3], b[3], a[4], b[4], a[5], b[5])
+    d32 = mixedgemm.matmul(*args, rounding="fused", out_dtype=torch.float32)
+    assert d32.dtype == torch.float32 and tuple(d32.shape) == (m, n)
+    # rounding the fp32 result once gives the bf16 result of the fused mode, bit for bit (same kernel, same accumulator)
+    assert torch.equal(d32.to(torch.bfloat16), mixedgemm.matmul(*args, rounding="fused"))
+    # and the fp32 values follow the oracle's fp64 sums within the hardware's block-sum error
+    _, f64 = o.matmul(qx[0], qw[0], qx[1], qw[1], qx[2], qw[2], qx[3], qw[3], qx[4], qw[4], qx[5], qw[5], rounding="fused", return_f64=True)
+    _, segs = o.matmul(qx[0], qw[0], qx[1], qw[1], qx[2], qw[2], qx[3], qw[3], qx[4], qw[4], qx[5], qw[5], rounding="fused", return_parts=True)
+    S = sum(np.abs(pa) @ np.abs(pb).T for _, pa, pb in segs)
+    got = d32.cpu().numpy().astype(np.float64)
+    assert np.all(np.abs(got - f64) <= 2.0 ** -11 * S + 2.0 ** -22 * np.abs(f64) + 1e-30)
+    with pytest.raises(ValueError):
+        mixedgemm.matmul(*args, out_dtype=torch.float32)                       # reference rounding: refused
+    with pytest.raises(ValueError):
+        mixedgemm.matmul(*args, rounding="fused", out_dtype=torch.float32, bias=torch.zeros(n, dtype=torch.bfloat16, device=dev))
+
+
 def test_split_k_is_deterministic_and_keeps_bias(dev):
     import torch
     rng = np.random.default_rng(77)

@@ -65,6 +65,11 @@ class OracleOps:
             return out
         return t
 
+    @staticmethod
+    def matmul_f32(a, b, out=None):
+        _, t = o.matmul(a[0], b[0], a[1], b[1], a[2], b[2], a[3], b[3], a[4], b[4], a[5], b[5], rounding="fused", return_f64=True)
+        return torch.from_numpy(t.astype(np.float32))
+
     @classmethod
     def activate_quantize(cls, a, b, kn, ks, ko):
         return o.activate_quantize(cls._bits(a), cls._bits(b), kn, ks, ko)
@@ -91,7 +96,8 @@ def _worker(rank, world, port, ret):
         layer = tp.TPShardedLinear(w, idx, *split, rank=rank, world=world, group=dist.group.WORLD, ops=OracleOps)
         y = layer(x.reshape(2, m // 2, k))
         assert y.shape == (2, m // 2, n)
-        ret[rank] = (layer.shard_widths, y.reshape(m, n).float().numpy())
+        y32 = layer(x.reshape(2, m // 2, k), fp32_partials=True)        # fp32 partial sums, one bf16 rounding after the all-reduce
+        ret[rank] = (layer.shard_widths, y.reshape(m, n).float().numpy(), y32.reshape(m, n).float().numpy())
     finally:
         dist.destroy_process_group()
 
@@ -119,6 +125,11 @@ def test_two_rank_gloo_matches_unsharded_oracle():
     S = sum(np.abs(ai).astype(np.float64) @ np.abs(bi).astype(np.float64).T for ai, bi in zip(a, b))
     assert np.all(np.abs(got - f64) <= 2.0 ** -7 * (np.abs(f64) + 0.25 * S) + 1e-30)
     assert np.linalg.norm(got - f64) / np.linalg.norm(f64) < 4e-3
+    # fp32 partials: the sum of the ranks' fp32 accumulators rounded ONCE = the unsharded fused product up to the fp32 rounding of
+    # the partial sums (at most one bf16 ulp apart, and almost always equal)
+    assert np.array_equal(res[0][2], res[1][2])
+    ulp = o.bf16_ulp_distance(o.f32_to_bf16(res[0][2].astype(np.float32)), want)
+    assert ulp.max() <= 1 and (ulp > 0).mean() < 0.01
 
 
 def _worker_chunked(rank, world, port, ret):

@@ -22,6 +22,7 @@ def test_sharded_sum_equals_unsharded(dev, world, split):
     b = mixedgemm.reorder_quantize_w4(w, idx, *split)
     full = mixedgemm.matmul(a[0], b[0], a[1], b[1], a[2], b[2], a[3], b[3], a[4], b[4], a[5], b[5], rounding="fused").float()
     total = torch.zeros((m, n), dtype=torch.float32, device=dev)
+    total32 = torch.zeros((m, n), dtype=torch.float32, device=dev)
     cols = 0
     for r in range(world):
         layer = tp.TPShardedLinear(w, idx, *split, rank=r, world=world)
@@ -34,7 +35,13 @@ def test_sharded_sum_equals_unsharded(dev, world, split):
         if w0:
             assert torch.equal(qx[2], a[2][:, s0:s0 + w0]) and torch.equal(layer.packed_w[2], b[2][:, s0 // 2:(s0 + w0) // 2])
         total += layer.ops.matmul(qx, layer.packed_w).float()
+        total32 += layer.ops.matmul_f32(qx, layer.packed_w)
     assert cols == k
+    # fp32 partial sums (MM_OUT_F32), one bf16 rounding after the sum: within ONE bf16 ulp of the unsharded fused product
+    # whatever the world size (the fp32 additions associate differently from the single accumulator, nothing more)
+    y32 = total32.to(torch.bfloat16).float()
+    assert float((y32 - full).abs().max()) <= 2.0 ** -8 * float(full.abs().max())
+    assert float((y32 != full).float().mean()) < 0.02
     # every partial is rounded to bf16 ONCE (tp.SHARD_ROUNDING = "fused"): |sum of partials - full| <= world half-ulps (2^-9
     # relative each) of the largest partial, plus the half-ulp of `full` itself
     err = (total - full).abs()
