@@ -233,6 +233,8 @@ int mm_diag_set_kernel_events(void *start_event, void *stop_event);
 /* device buffer of 4 x 8 bytes per workgroup: {main-loop s_memtime delta, main-loop s_memrealtime delta, start tick,
  * end-of-epilogue tick delta} of every workgroup of the large-M GEMM (in-kernel clock = ratio x 100 MHz); NULL disables. */
 int mm_diag_set_clock_buffer(void *buf);
+/* device buffer of 4 x 8 bytes per workgroup of reorder_quantize_kernel: {start, row staged, first group stored, end} ticks */
+int mm_diag_set_quant_clock_buffer(void *buf);
 #endif
 
 #ifdef __cplusplus

@@ -333,6 +333,7 @@ int mm_diag_set_kernel_events(void *start_event, void *stop_event) {
 }
 
 #ifdef MM_INSTRUMENT
+int mm_diag_set_quant_clock_buffer(void *buf) { return mm::set_quant_clock_buffer((unsigned long long *)buf) == hipSuccess ? MM_OK : MM_ERR_LAUNCH; }
 // only in the instrumented variant (csrc/mx_instrument.h): the default library has neither this symbol nor the in-kernel stores
 int mm_diag_set_clock_buffer(void *buf) {
     g_clock_buf = (unsigned long long *)buf;

@@ -93,6 +93,7 @@ struct GroupedQuantArgs {
 };
 hipError_t launch_reorder_quantize_grouped(const GroupedQuantArgs &ga, int max_rows, bool w4, hipStream_t stream);
 
+hipError_t set_quant_clock_buffer(unsigned long long *buf);   // -DMM_INSTRUMENT only
 hipError_t launch_reorder_quantize(const void *src, int rows, int K, const int16_t *idx, int KN, int KS, int KO, bool w4,
                                    uint8_t *oN, uint8_t *oS, uint8_t *oO, uint8_t *sfN, uint8_t *sfS, uint8_t *sfO,
                                    hipStream_t stream);

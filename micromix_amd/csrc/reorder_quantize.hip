@@ -17,9 +17,15 @@
 //    one hardware MX-converter instruction per 2 (fp4/fp8) or 32 (fp6) elements.
 #include "mx_common.h"
 #include "mx_group_convert.h"
+#include "mx_instrument.h"
 #include "mx_kernels.h"
 
 namespace mm {
+
+#if MM_CLOCKS
+// instrumented variant only: per workgroup {start, row staged, group quantized and stored, end} in 100 MHz ticks (tools/quant_clock.py)
+__device__ unsigned long long *g_quant_clock = nullptr;
+#endif
 
 // rows first_row, first_row + row_stride, ... of one [rows, K] matrix (one workgroup's share)
 template <bool W4>
@@ -53,6 +59,10 @@ __device__ __forceinline__ void reorder_quantize_body(const uint16_t *__restrict
     else if (g < gN + gS) { seg = 1; j = g - gN; kseg = KS; }
     else { seg = 2; j = g - gN - gS; kseg = KO; }
 
+#if MM_CLOCKS
+    unsigned long long *ck = g_quant_clock != nullptr ? g_quant_clock + 4 * (size_t)blockIdx.x : nullptr;
+    if (ck != nullptr && threadIdx.x == 0) ck[0] = __builtin_amdgcn_s_memrealtime();
+#endif
     uint4 stage[4];
     int r = first_row;
     if (r < rows) {
@@ -71,6 +81,9 @@ __device__ __forceinline__ void reorder_quantize_body(const uint16_t *__restrict
         }
     }
     __syncthreads();
+#if MM_CLOCKS
+    if (ck != nullptr && threadIdx.x == 0) ck[1] = __builtin_amdgcn_s_memrealtime();
+#endif
     for (; r < rows; r += row_stride) {
         const int rn = r + row_stride;
         if (rn < rows) {
@@ -107,6 +120,9 @@ __device__ __forceinline__ void reorder_quantize_body(const uint16_t *__restrict
             if ((g & 3) == 0)
                 *reinterpret_cast<uint32_t *>(sf + sf_offset(r, j, kseg)) = byte | (b1 << 8) | (b2 << 16) | (b3 << 24);
         }
+#if MM_CLOCKS
+        if (ck != nullptr && threadIdx.x == 0 && r == first_row) ck[2] = __builtin_amdgcn_s_memrealtime();
+#endif
         __syncthreads();
         if (rn < rows) {
 #pragma unroll
@@ -117,6 +133,12 @@ __device__ __forceinline__ void reorder_quantize_body(const uint16_t *__restrict
         }
         __syncthreads();
     }
+#if MM_CLOCKS
+    if (ck != nullptr && threadIdx.x == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ck[3] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
 }
 
 template <bool W4, int MAXT>
@@ -136,6 +158,10 @@ __global__ void __launch_bounds__(MAXT) reorder_quantize_grouped_kernel(GroupedQ
         reorder_quantize_body<W4>(q.src, q.rows, ga.K, q.idx, ga.KN, ga.KS, ga.KO, q.o[0], q.o[1], q.o[2], q.sf[0], q.sf[1], q.sf[2],
                                   blockIdx.x, gridDim.x);
 }
+
+#if MM_CLOCKS
+hipError_t set_quant_clock_buffer(unsigned long long *buf) { return hipMemcpyToSymbol(HIP_SYMBOL(g_quant_clock), &buf, sizeof(buf)); }
+#endif
 
 hipError_t launch_reorder_quantize(const void *src, int rows, int K, const int16_t *idx, int KN, int KS, int KO, bool w4,
                                    uint8_t *oN, uint8_t *oS, uint8_t *oO, uint8_t *sfN, uint8_t *sfS, uint8_t *sfO,
