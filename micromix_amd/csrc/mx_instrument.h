@@ -4,7 +4,8 @@
 //     tools/build_variant.sh instr -DMM_INSTRUMENT [-DMM_DBG=<bits>]      -> micromix_amd/lib/dbg/lib_instr.so
 // and selected with MICROMIX_HIP_LIB=<path> (tools/gemm_clock.py picks lib_instr.so up by itself).
 //   MM_DBG bits (ablations, results are garbage): 1 = no MFMA, 2 = no DMA, 512 = no fragment reads in the loop;
-//   1024 = no workgroup barriers, 2048 = no waits for the DMA; 64-row tiles: 4 = no global loads, 8 = no LDS writes, 32 = no fragment reads.
+//   1024 = no workgroup barriers, 2048 = no waits for the DMA, 4096 = every workgroup loads tile (0,0)'s operands (no L2 misses),
+//   8192 = every workgroup loads its XCD's first tile's operands; 64-row tiles: 4 = no global loads, 8 = no LDS writes, 32 = no fragment reads.
 #pragma once
 #ifdef MM_INSTRUMENT
 #ifndef MM_DBG

@@ -1,6 +1,6 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_matmul_gpu.py -x -q -k "full_size or every_tile or golden or matches_oracle" 2>&1 | tail -3
-timeout 900 python -m pytest tests/test_model_shapes_gpu.py -x -q -k "llama_projection" 2>&1 | tail -3
-tools/run_variants.sh "tools/gemm_clock.py 2048,128,1920 3072,896,128" nohook instr nohook instr > gpurun_out/r03_hook.txt 2>&1
-tools/run_variants.sh "tools/gemm_clock.py K=14336 12288,1024,1024" nohook instr >> gpurun_out/r03_hook.txt 2>&1
-grep -E "===|loop cycles" gpurun_out/r03_hook.txt
+bash tools/profile.sh r03 > gpurun_out/profile_r03.log 2>&1
+tail -5 gpurun_out/profile_r03.log
+python tools/bench_shapes.py 1 16 128 256 512 2048 4096 2>&1 | grep -v amdgpu.ids > gpurun_out/r03_llama_shapes.txt
+python tools/bench_tp_configs.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r03_tp_configs.txt
+tail -3 gpurun_out/r03_llama_shapes.txt gpurun_out/r03_tp_configs.txt

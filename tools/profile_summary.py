@@ -14,8 +14,8 @@ for f in glob.glob(out + "/trace/*/*_kernel_stats.csv"):
     for r in rows:
         lines.append(f"{r['Name'][:70]:70s} calls {r['Calls']:>5s} avg {float(r['AverageNs'])/1e3:8.2f} us min {float(r['MinNs'])/1e3:8.2f} max {float(r['MaxNs'])/1e3:8.2f} {float(r['Percentage']):6.2f}%")
 # The headline GEMM (4096^3, split (0,0,4096), w4) = the first uninterrupted run of launches of the 256x256-tile kernel: warm-up,
-# graph capture warm-up, first graph replay, the settle phase, the timed graph replay, the stream-launch pass and, last, the pass
-# with HIP events attached (`roofline.kernel_us`, `steps` launches).  Anything after the next quantizer launch is another split.
+# graph capture warm-up, first graph replay, the settle phase, the timed stream-launch pass (`value`), the graph replay and, last,
+# the pass with HIP events attached (`roofline.kernel_us`, `steps` launches).  Anything after the next quantizer launch is another split.
 for f in glob.glob(out + "/trace/*/*_kernel_trace.csv"):
     rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
     run, started = [], False
@@ -29,8 +29,8 @@ for f in glob.glob(out + "/trace/*/*_kernel_trace.csv"):
     if len(run) >= 60:
         steps = 20
         lines.append(f"headline GEMM: {len(run)} consecutive launches in the trace; ALL: avg {sum(run)/len(run):.2f} us min {min(run):.2f} max {max(run):.2f}")
-        for name, t in (("event pass (last 20 launches = roofline.kernel_us)", run[-steps:]), ("stream-launch pass (20 launches before those)", run[-2 * steps:-steps]),
-                        ("timed region (hipGraph replay, 20 launches before those)", run[-3 * steps:-2 * steps]), ("first 26 launches (warm-up, on the clock ramp)", run[:26])):
+        for name, t in (("event pass (last 20 launches = roofline.kernel_us)", run[-steps:]), ("hipGraph replay (auxiliary figure, 20 launches before those)", run[-2 * steps:-steps]),
+                        ("timed region (`value`: K stream launches, 20 launches before those)", run[-3 * steps:-2 * steps]), ("first 26 launches (warm-up, on the clock ramp)", run[:26])):
             lines.append(f"  {name}: kernel-trace avg {sum(t)/len(t):.2f} us min {min(t):.2f} max {max(t):.2f}")
 bench_line = [l for l in open(out + "/bench_under_rocprof.log") if l.startswith("{")]
 if bench_line:
@@ -41,7 +41,7 @@ if plain:
     lines.append(f"== bench.py JSON line of an unprofiled run of the same command on the same box ({CMD}) ==")
     lines.append(plain[-1].strip())
 traffic = None
-for name in ("fp8", "fp4", "mixed"):
+for name in ("fp8", "fp4", "mixed", "mixed3072", "down"):
     d = os.path.join(root, "gpurun_out", f"pmc_{tag}_{name}")
     agg = collections.defaultdict(list)
     for f in glob.glob(d + "/*/*/*_counter_collection.csv"):
