@@ -144,16 +144,21 @@ def reorder_quantize_w4(W, reorder_index, KN, KS, KO):
 
 
 _SPLIT_WS = {}
+_SPLIT_WS_RETIRED = []     # outgrown workspaces stay alive: a captured hipGraph may still hold their address
 
 
 def split_workspace(dev, nbytes):
     """The split-K scratch of `dev`'s current stream: one tensor per (device, stream), grown when a shape needs more, its first
     MM_WS_TICKET_BYTES zero (the C ABI's MM_WS_TICKETS_ZEROED contract: cleared once here, left zero by every launch).  Reuse by
-    consecutive launches of one stream is ordered by the stream; the C ABI itself never allocates."""
+    consecutive launches of one stream is ordered by the stream; the C ABI itself never allocates.  A workspace that a later,
+    larger shape outgrows is replaced but never freed (sizes at least double, so the total stays below twice the largest)."""
     key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
     t = _SPLIT_WS.get(key)
     if t is None or t.numel() < nbytes:
-        t = torch.empty((max(int(nbytes), 8 << 20),), dtype=torch.uint8, device=dev)
+        if t is not None:
+            _SPLIT_WS_RETIRED.append(t)
+        size = max(int(nbytes), 8 << 20, 2 * t.numel() if t is not None else 0)
+        t = torch.empty((size,), dtype=torch.uint8, device=dev)
         t[:_lib.MM_WS_TICKET_BYTES].zero_()
         _SPLIT_WS[key] = t
     return t
