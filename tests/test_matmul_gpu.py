@@ -389,6 +389,39 @@ def test_every_tile_kernel(dev, ns, tile, M, N, wmode):
         check_gemm(bits_from_t(d)[rows], qx, [u8(t) for t in b], rounding, label=f"{ns} {M}x{N} {wmode} {rounding}")
 
 
+# Chained segment hand-over of the 256-row tile (run_slabs_big, fp4 weights): every way a segment can pass its successor's first slabs
+# on -- fp4 ring of 2 / 3 / 6 slabs into S or straight into O, successors shorter than, equal to and longer than their ring, S -> O
+# through one ring, a segment shorter than the ring that owes its successor's slabs, and the cases that must NOT chain (odd fp4
+# width, fewer than two 256-deep slabs).  Both weight modes (the matching-precision kernel keeps every segment's own prologue).
+CHAIN_SPLITS = [(512, 128, 128), (512, 256, 384), (768, 0, 512), (1024, 384, 0), (640, 128, 256), (0, 384, 512), (0, 128, 128),
+                (512, 128, 640), (1536, 128, 128), (256, 128, 256), (512, 0, 128), (512, 384, 128), (0, 128, 1024), (1536, 512, 0)]
+
+
+@pytest.mark.parametrize("wmode", ("w4", "w"))
+@pytest.mark.parametrize("split", CHAIN_SPLITS, ids=["_".join(map(str, c)) for c in CHAIN_SPLITS])
+def test_chained_segments_on_256_row_tiles(dev, split, wmode):
+    import torch
+    from micromix_amd import _lib
+    M, N, K = 3900, 4090, sum(split)
+    desc = _lib.load().mm_matmul_describe(M, N, *split, 1 if wmode == "w4" else 0, 0, 0).decode()
+    assert "mm::g256::" in desc, desc
+    rng = np.random.default_rng(K + split[0] + 7 * split[1])
+    xb = make_inputs(rng, M, K)
+    wb = make_inputs(rng, N, K, "weight")
+    idx = rng.permutation(K).astype(np.int16)
+    x, w, tidx = t_from_bits(xb, dev), t_from_bits(wb, dev), torch.from_numpy(idx).to(dev)
+    a = mixedgemm.reorder_quantize_x(x, tidx, *split)
+    b = (mixedgemm.reorder_quantize_w4 if wmode == "w4" else mixedgemm.reorder_quantize_w)(w, tidx, *split)
+    rows = np.unique(np.concatenate([rng.choice(M, 20, replace=False), [0, 255, 256, M - 1]]))
+    qx = o.reorder_quantize(xb[rows], idx, *split, "x")
+    qw = [u8(t) for t in b]
+    wdeq = o.dequant_operand(qw, "w", wmode)
+    for rounding in ("reference", "fused"):
+        d = mixedgemm.matmul(a[0], b[0], a[1], b[1], a[2], b[2], a[3], b[3], a[4], b[4], a[5], b[5], rounding=rounding)
+        assert torch.equal(d, mixedgemm.matmul(a[0], b[0], a[1], b[1], a[2], b[2], a[3], b[3], a[4], b[4], a[5], b[5], rounding=rounding))
+        check_gemm(bits_from_t(d)[rows], qx, qw, rounding, label=f"chained {split} {wmode} {rounding}", wdeq=wdeq)
+
+
 def _boundary_shapes():
     """token / feature counts on both sides of every dispatch threshold of mx_gemm.hip / plan_tiles (16 | 32 | 64 rows for the
     skinny kernels, N / 32 against the CUs, the 64x64 / 64x128 / 128x128 / 128x256 tile rounds), with ragged edges"""

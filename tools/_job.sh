@@ -1,3 +1,2 @@
 cd $GRAFT_REPO_ROOT
-timeout 3000 python -m pytest tests/ -x -q -m gpu 2>&1 | tail -8
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+timeout 900 python -m pytest tests/test_matmul_gpu.py -x -q -k "chained_segments" 2>&1 | tail -6
