@@ -211,13 +211,21 @@ def main():
         return mixedgemm.matmul(a[0], b[0], a[1], b[1], a[2], b[2], a[3], b[3], a[4], b[4], a[5], b[5], out=out)
 
     def settle(fn, seconds=SETTLE_S):
-        """untimed: back-to-back launches for at least `seconds` so that the clock the timed region sees is the sustained one"""
+        """untimed: back-to-back launches for at least `seconds` so that the clock the timed region sees is the sustained one.
+        With several ranks the steps contain collectives, so every rank must run the SAME number of batches: the decision to
+        go on is taken on the maximum of the ranks' elapsed times (one tiny all-reduce per batch)."""
         t0 = time.perf_counter()
-        while time.perf_counter() - t0 < seconds:
+        while True:
             for _ in range(100):
                 fn()
             torch.cuda.synchronize()
-        return time.perf_counter() - t0
+            elapsed = time.perf_counter() - t0
+            if world > 1:
+                t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                elapsed = float(t.item())
+            if elapsed >= seconds:
+                return elapsed
 
     def kernel_us(fn, steps, stat=np.mean):
         """mean duration of the tiled-GEMM dispatch inside fn(): HIP events attached to the dispatch itself (hipExtLaunchKernel
