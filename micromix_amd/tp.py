@@ -316,24 +316,26 @@ class TPMLP:
     def quantize_x(self, x2d: torch.Tensor):
         return self.ops.quantize_x(x2d, self.in_index, *self.in_split)
 
-    def partial(self, qx) -> torch.Tensor | None:
-        """this rank's [M, H] partial of the MLP output (None for an empty shard)"""
+    def partial(self, qx, fp32: bool = False) -> torch.Tensor | None:
+        """this rank's [M, H] partial of the MLP output (None for an empty shard); fp32 = the unrounded accumulator (MM_OUT_F32)"""
         if self.empty:
             return None
         g = self.ops.matmul(qx, self.packed_gate, rounding="reference")
         u = self.ops.matmul(qx, self.packed_up, rounding="reference")
         qh = self.ops.activate_quantize(g, u, *self.widths)
-        return self.ops.matmul(qh, self.packed_down)
+        return self.ops.matmul_f32(qh, self.packed_down) if fp32 else self.ops.matmul(qh, self.packed_down)
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, fp32_partials: bool = False) -> torch.Tensor:
+        """fp32_partials: the ranks' partial sums travel and add as fp32 and are rounded to bf16 once (twice the bytes on the wire,
+        a result within one bf16 ulp of the unsharded fused product whatever the world size)"""
         import torch.distributed as dist
         lead = x.shape[:-1]
         x2 = x.reshape(-1, self.H).contiguous()
-        part = self.partial(self.quantize_x(x2))
+        part = self.partial(self.quantize_x(x2), fp32=fp32_partials)
         if part is None:
-            part = torch.zeros((x2.shape[0], self.H), dtype=torch.bfloat16, device=x2.device)
+            part = torch.zeros((x2.shape[0], self.H), dtype=torch.float32 if fp32_partials else torch.bfloat16, device=x2.device)
         if self.world > 1:
             dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.group)
-        return part.reshape(*lead, self.H)
+        return part.to(torch.bfloat16).reshape(*lead, self.H)
 
     __call__ = forward

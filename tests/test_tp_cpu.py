@@ -181,10 +181,12 @@ def _worker_mlp(rank, world, port, ret):
         m, h, inter, in_split, down_split, x, wg, wu, wd, idx = _mlp_inputs()
         mlp = tp.TPMLP(wg, wu, wd, idx, in_split, down_split, rank=rank, world=world, group=dist.group.WORLD, ops=OracleOps)
         y = mlp(x.reshape(2, m // 2, h))
+        y32 = mlp(x.reshape(2, m // 2, h), fp32_partials=True)
         col = tp.ColumnParallelLinear(wg, idx, *in_split, rank=rank, world=world, group=dist.group.WORLD, ops=OracleOps,
                                       gather_output=True)
         g = col(x)
-        ret[rank] = (mlp.widths, y.reshape(m, h).float().numpy(), g.float().numpy(), col.features.numpy())
+        ret[rank] = (mlp.widths, y.reshape(m, h).float().numpy(), g.float().numpy(), col.features.numpy(),
+                     y32.reshape(m, h).float().numpy())
     finally:
         dist.destroy_process_group()
 
@@ -219,6 +221,10 @@ def test_two_rank_gloo_megatron_mlp_and_column_parallel():
     S = sum(np.abs(ai).astype(np.float64) @ np.abs(bi).astype(np.float64).T for ai, bi in zip(a, b))
     assert np.all(np.abs(got - f64) <= 2.0 ** -7 * (np.abs(f64) + 0.25 * S) + 1e-30)
     assert np.linalg.norm(got - f64) / np.linalg.norm(f64) < 4e-3
+    # fp32 partial sums: one bf16 rounding after the all-reduce = the unsharded fused product to within one ulp
+    assert np.array_equal(res[0][4], res[1][4])
+    ulp = o.bf16_ulp_distance(o.f32_to_bf16(res[0][4].astype(np.float32)), want)
+    assert ulp.max() <= 1 and (ulp > 0).mean() < 0.01
 
 
 def test_shard_positions_partition_the_intermediate_features():

@@ -64,6 +64,8 @@ def main():
     mlp = tp.TPMLP(wg, wu, wd, idh, in_split, down_split, rank=rank, world=world, group=dist.group.WORLD)
     ym = mlp(xs).float()
     assert float((ym - ref).abs().max()) <= bound(ref), ("TPMLP", float((ym - ref).abs().max()), bound(ref))
+    ym32 = mlp(xs, fp32_partials=True).float()
+    assert float((ym32 - ref).abs().max()) <= 2.0 ** -8 * float(ref.abs().max()) + 1e-3, ("TPMLP fp32", float((ym32 - ref).abs().max()))
     dist.barrier()
     torch.cuda.synchronize()
     print(f"RCCL-OK rank {rank}", flush=True)
