@@ -1,4 +1,5 @@
-"""A short, seeded run of the randomised stress tools (tools/stress.py, tools/stress_grouped.py): run-to-run determinism of every
+"""A short, seeded run of the randomised stress tools (tools/stress.py, tools/stress_grouped.py, tools/stress_split.py: the split-K that
+reduces inside the launch, alternating shapes through one workspace and a second stream): run-to-run determinism of every
 GEMM path and agreement between paths on random shapes, splits and weight modes.  The long runs are a tool; this keeps a slice of
 them in the suite (a 4-minute run is what found the 64x128-tile register bug of round 2)."""
 import os
@@ -11,7 +12,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("tool,seconds", [("stress.py", 20), ("stress_grouped.py", 12)])
+@pytest.mark.parametrize("tool,seconds", [("stress.py", 20), ("stress_grouped.py", 12), ("stress_split.py", 12)])
 def test_seeded_stress_slice(dev, tool, seconds):
     env = dict(os.environ, STRESS_SEED="12345")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool), str(seconds)], env=env, capture_output=True, text=True,
