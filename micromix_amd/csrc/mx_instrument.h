@@ -5,7 +5,7 @@
 // and selected with MICROMIX_HIP_LIB=<path> (tools/gemm_clock.py picks lib_instr.so up by itself).
 //   MM_DBG bits (ablations, results are garbage): 1 = no MFMA, 2 = no DMA, 512 = no fragment reads in the loop;
 //   1024 = no workgroup barriers, 2048 = no waits for the DMA, 4096 = every workgroup loads tile (0,0)'s operands (no L2 misses),
-//   8192 = every workgroup loads its XCD's first tile's operands; 64-row tiles: 4 = no global loads, 8 = no LDS writes, 32 = no fragment reads.
+//   8192 = every workgroup loads its XCD's first tile's operands, 16384 = 128-byte operand rows fetched as half lines; 64-row tiles: 4 = no global loads, 8 = no LDS writes, 32 = no fragment reads.
 #pragma once
 #ifdef MM_INSTRUMENT
 #ifndef MM_DBG
