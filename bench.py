@@ -53,6 +53,7 @@ M = N = K = 4096
 SPLIT = (0, 0, 4096)          # (p4_num, p6_num, p8_num): all-MXFP8 activations
 PEAK_TFLOPS_FP8 = 5033.0      # 2048 flop/clk/SIMD * 4 SIMD * 256 CU * 2.4 GHz (MI355X_MICROARCH.md, dense)
 PEAK_TFLOPS_FP4 = 10066.0     # fp6 / fp4 operands: 4096 flop/clk/SIMD
+SUSTAINED_MFMA_FP8_FP4 = 4398.0   # measured: register-operand fp8 x fp4 32x32x64 MFMA loop, DVFS-settled (profiles/r02_mfma_shapes.txt)
 SETTLE_S = 1.5
 # mixed splits of SURVEY.md section 8d (name, M, N, K, split)
 MIXED = [("q_o_2048_128_1920", 4096, 4096, 4096, (2048, 128, 1920)), ("q_o_3072_896_128", 4096, 4096, 4096, (3072, 896, 128)),
@@ -350,6 +351,10 @@ def main():
             "algorithmic_flop_per_launch": flop,
             "algorithmic_bytes_per_launch": M * K + N * K // 2 + (M + N) * K // 32 + 2 * M * N,
             "note": "peak = dense fp8-operand scaled-MFMA rate; A is fp8 so the fp8 rate applies to the whole launch",
+            # context, not part of the contract: what a loop of nothing but register-operand fp8 x fp4 MFMAs sustains on this chip
+            # at its 1400 W package cap (tools/mfma_energy.py, profiles/r02_mfma_shapes.txt) -- the tiled GEMM runs AT that cap
+            # (`power`), see DESIGN.md section 4.2
+            "sustained_mfma_only_tflops": SUSTAINED_MFMA_FP8_FP4, "frac_of_sustained_mfma_only": round(achieved / SUSTAINED_MFMA_FP8_FP4, 4),
         }
     if rank == 0 and world == 1 and not args.no_extras:
         # ---- mixed splits against their per-precision rooflines (t* = sum_seg 2*M*N*K_seg / peak(seg)) ----
