@@ -65,7 +65,8 @@ enum mm_matmul_flags {
     MM_OUT_F32 = 8,           /* mm_matmul / mm_matmul_ws: D is [M,N] FP32 and receives the fp32 accumulator itself, unrounded.  For the
                                  partial products of a K-sharded (row-parallel) tensor-parallel layer: the ranks' partials are summed in
                                  fp32 and rounded to bf16 once, so the result does not degrade with the number of ranks.  Needs
-                                 MM_ROUND_ONCE and bias_bf16 == NULL (the bias is added after the reduction). */
+                                 MM_ROUND_ONCE and bias_bf16 == NULL (the bias is added after the reduction); mm_matmul_grouped and mm_qlinear_decode
+                                 return MM_ERR_UNSUPPORTED for it. */
     MM_WS_TICKETS_ZEROED = 4  /* mm_matmul_ws / mm_matmul_workspace_bytes / mm_matmul_describe: the first MM_WS_TICKET_BYTES of the
                                  workspace are ZERO (the caller cleared them once, when it created the workspace; every launch
                                  leaves them zero again).  Enables the split-K whose reduction runs inside the GEMM launch (64-row

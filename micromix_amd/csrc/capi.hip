@@ -120,6 +120,7 @@ int mm_qlinear_decode(const void *X_bf16, const int16_t *reorder_index, const ui
     if (M < 0 || N < 0 || KN < 0 || KS < 0 || KO < 0) return MM_ERR_BAD_ARG;
     if ((KN % 128) || (KS % 128) || (KO % 128) || KN + KS + KO == 0) return MM_ERR_BAD_SPLIT;
     if (wmode != MM_W_MATCH && wmode != MM_W_FP4) return MM_ERR_BAD_ARG;
+    if (flags & MM_OUT_F32) return MM_ERR_UNSUPPORTED;    // fp32 partial sums come from mm_matmul only
     if (M == 0 || N == 0) return MM_OK;
     if (!mm_qlinear_decode_supported(M, N, KN, KS, KO)) return MM_ERR_UNSUPPORTED;
     if (!X_bf16 || !reorder_index || !D_bf16) return MM_ERR_BAD_ARG;
@@ -247,6 +248,7 @@ int mm_matmul_grouped(const mm_group *groups, int ngroups, int N, int KN, int KS
     if (ngroups < 0 || N < 0 || KN < 0 || KS < 0 || KO < 0 || (ngroups > 0 && !groups)) return MM_ERR_BAD_ARG;
     if ((KN % 128) || (KS % 128) || (KO % 128)) return MM_ERR_BAD_SPLIT;
     if (wmode != MM_W_MATCH && wmode != MM_W_FP4) return MM_ERR_BAD_ARG;
+    if (flags & MM_OUT_F32) return MM_ERR_UNSUPPORTED;    // fp32 partial sums come from mm_matmul only
     if (ngroups == 0 || N == 0) return MM_OK;
     for (int i = 0; i < ngroups; ++i) {
         const mm_group &g = groups[i];

@@ -58,6 +58,12 @@ def test_host_helpers_match_oracle():
 def test_status_codes_without_device_work():
     lib = _lib.load()
     z = None
+    # MM_OUT_F32 belongs to mm_matmul: the grouped and the fused-decode entries refuse it, and mm_matmul refuses it without
+    # MM_ROUND_ONCE or with a bias (checked before any pointer is touched)
+    assert lib.mm_matmul_grouped(None, 0, 128, 128, 0, 0, 1, _lib.MM_OUT_F32 | _lib.MM_ROUND_ONCE, None) == _lib.MM_ERR_UNSUPPORTED
+    assert lib.mm_qlinear_decode(*([None] * 8), 1, 128, 128, 0, 0, 1, _lib.MM_OUT_F32 | _lib.MM_ROUND_ONCE, None, None, None) == _lib.MM_ERR_UNSUPPORTED
+    assert lib.mm_matmul(*([1] * 12), 8, 128, 128, 0, 0, 1, _lib.MM_OUT_F32, None, 1, None) == _lib.MM_ERR_BAD_ARG
+    assert lib.mm_matmul(*([1] * 12), 8, 128, 128, 0, 0, 1, _lib.MM_OUT_F32 | _lib.MM_ROUND_ONCE, 1, 1, None) == _lib.MM_ERR_BAD_ARG
     # bad splits are rejected before any pointer is touched (reference: "Value error in run_reorder_quantize_x")
     for K, kn, ks, ko in ((4096, 100, 0, 3996), (4096, 2048, 1024, 512), (0, 0, 0, 0), (256, -128, 128, 256)):
         assert lib.mm_reorder_quantize(z, 4, K, z, kn, ks, ko, 0, z, z, z, z, z, z, z) == _lib.MM_ERR_BAD_SPLIT
