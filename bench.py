@@ -400,6 +400,22 @@ def main():
             few[f"q_o_M{m_}"] = {"M": m_, "N": N, "K": K, "split": list(fsplit), "kernel_us": round(us, 2), "kernel_us_stat": "median",
                                  "tflops": round(2.0 * m_ * N * K / us / 1e6, 1),
                                  "kernel": lib.mm_matmul_describe(m_, N, *fsplit, 1, 0, 0).decode()}
+        # k/v projection (N = 1024): at M = 128 its 32 tiles take the split-K that reduces inside the launch (mixedgemm.matmul keeps
+        # the zeroed ticket workspace); the same shape with split_k=False beside it
+        wkv = w[:1024].contiguous()
+        bkv = mixedgemm.reorder_quantize_w4(wkv, idx, *fsplit)
+        for m_ in (128, 256):
+            akv = mixedgemm.reorder_quantize_x(x[:m_].contiguous(), idx, *fsplit)
+            okv = torch.empty((m_, 1024), dtype=torch.bfloat16, device=dev)
+            ent = {"M": m_, "N": 1024, "K": K, "split": list(fsplit), "kernel_us_stat": "median"}
+            for key, kw in (("kernel_us", {}), ("kernel_us_unsplit", {"split_k": False})):
+                f = lambda: mixedgemm.matmul(akv[0], bkv[0], akv[1], bkv[1], akv[2], bkv[2], akv[3], bkv[3], akv[4], bkv[4], akv[5], bkv[5], out=okv, **kw)
+                settle(f, 0.2)
+                ent[key] = round(kernel_us(f, args.steps, np.median), 2)
+            need = lib.mm_matmul_workspace_bytes(m_, 1024, *fsplit, 1, 4)
+            ent["kernel"] = lib.mm_matmul_describe(m_, 1024, *fsplit, 1, 4, need).decode()
+            few[f"k_v_M{m_}"] = ent
+        del bkv
         # ---- decode: one token through QLinearLayer.forward as ONE launch (mm_qlinear_decode: quantize + GEMM fused, M <= 8) ----
         dec = {}
         xd = x[:1].contiguous()
