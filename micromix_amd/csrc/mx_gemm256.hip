@@ -265,20 +265,22 @@ static int plan_splits(int M, int N, const int K[3], bool w4, bool force, int fi
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// In-kernel split-K of the 4-wave tiles (split_tile_reduce in mx_gemm_tile.inc): a launch whose 64 x 64 tiles occupy at most a
-// quarter of the CUs cuts K into `splits` equal slab ranges, one workgroup each, and the last workgroup of a tile to finish
+// In-kernel split-K of the 4-wave tiles (split_tile_reduce in mx_gemm_tile.inc): a launch whose 64 x 64 tiles occupy at most half
+// of the CUs cuts K into `splits` equal slab ranges, one workgroup each, and the last workgroup of a tile to finish
 // reduces.  Workspace: [tickets: MM_TICKET_BYTES, one 32-bit counter per tile, zero between launches][tiles x (<= splits + 2)
 // partial-sum slots].
-// What it is worth, measured on MI355X (tools/split_clock.py: kernel durations from dispatch events, phases from in-kernel clock
-// stamps; k/v projection N = 1024, K = 4096, M = 128, 32 tiles): unsplit 12.7 us; 2 / 4 / 6 / 8 splits 12.3 / 11.2 / 10.2 / 15.6 us.
-// A workgroup needs ~2.5-3.5 us from its start to its first finished slab and ~0.3 us per 128-deep slab after that; the split
-// adds ~0.6 us (partial sums acknowledged, ticket) and one round trip of ~2 us for the reducing workgroup's reads (the partial
-// sums are written through to memory: the eight XCDs' L2s are not coherent for plain accesses), so at K = 4096 a split saves at
-// most the slabs it removes minus ~3 us -- 2-2.5 us of 12.7 with six splits -- and nothing once the tiles alone fill half of
-// the chip (q/o, N = 4096, M = 128: 128 tiles, unsplit 12.9 us, 2 splits 14.1 us); with all 256 CUs busy loading it loses
-// (8 splits x 32 tiles: 15.6 us), and with 64 tiles (k/v at M = 256) two to four splits land within +-0.7 us of the unsplit
-// 12.3 us.  Hence the rule below: at most 48 tiles, four to six splits, at most 192 workgroups, at least four slabs per split.  MICROMIX_SPLIT_SMALL=0 disables it, =<tile>:<S> (tile 33 = 64 x 64, 32 = 64 x 128) pins a plan
-// (tools, tests); MM_SPLIT_K_ALWAYS relaxes the rule to "any split that fits one round of workgroups".
+// What it is worth, measured on MI355X.  Phases of ONE cold launch (tools/split_clock.py, in-kernel clock stamps): a workgroup needs
+// ~2.5-3.5 us from its start to its first finished slab and ~0.3 us per 128-deep slab after that; the split adds ~0.6 us (partial
+// sums acknowledged, ticket) and one round trip of ~2 us for the reducing workgroup's reads (the partial sums are written through to
+// memory: the eight XCDs' L2s are not coherent for plain accesses).  Kernel durations in a queue of back-to-back launches
+// (tools/split_small_sweep.py: dispatch events, settled; K = 4096, (2048,128,1920)), unsplit / 2 / 4 / 6 splits:
+//   32 tiles (k/v, N = 1024, M = 128)   11.3 / 10.7 /  9.5 /  8.9 us        64 tiles (N = 2048, M = 128)  12.7 / 11.2 / 11.5 / 15.2
+//   48 tiles (N = 1024, M = 192)        11.4 / 10.9 / 10.0 / 12.6           128 tiles (q/o, M = 128)      12.9 / 12.0 / 19.8 / 19.9
+//   64 tiles (N = 1024, M = 256)        11.2 / 11.2 / 10.8 / 13.9           256 tiles (q/o, M = 256)      12.8 / 22.7
+// More than one round of workgroups (tiles x splits > CUs) always loses.  Hence the rule below: six splits up to 32 tiles, four up
+// to 48, two up to 128, at least four slabs per split.  MICROMIX_SPLIT_SMALL=0 disables it, =<tile>:<S> (tile 33 = 64 x 64,
+// 32 = 64 x 128; the latter never won) pins a plan (tools, tests); MM_SPLIT_K_ALWAYS relaxes the rule to "any split that fits one
+// round of workgroups".
 // ---------------------------------------------------------------------------------------------------------
 struct SmallSplit {
     int kind;     // 0 = none, 33 = 64 x 64 tiles, 32 = 64 x 128 tiles
@@ -314,11 +316,14 @@ static SmallSplit plan_small_split(int M, int N, const int K[3], bool force) {
         }
         return none;
     }
-    if (t32n > 48) return none;
-    int S = 192 / t32n;
-    S = S > 6 ? 6 : S;
+    // measured rule (see above): six splits up to 32 tiles, four up to 48, two up to half a round of workgroups; never more than one
+    // round of workgroups, at least four slabs per split
+    // (longer K -- down_proj, 112 slabs -- stays with the two-launch split-K of the 128-row tiles, which cuts it into up to 16)
+    if (total > 64) return none;
+    int S = t32n <= 32 ? 6 : t32n <= 48 ? 4 : 2 * t32n <= cus ? 2 : 0;
     S = S > total / 4 ? total / 4 : S;
-    return S >= 4 ? SmallSplit{33, S, t32n} : none;
+    S = (S == 5 || S == 3) ? S - 1 : S;
+    return S >= 2 && t32n * S <= cus ? SmallSplit{33, S, t32n} : none;
 }
 
 size_t mx_gemm_workspace_bytes(int M, int N, const int K[3], bool w4, bool force, bool tickets_zeroed) {

@@ -137,7 +137,7 @@ def test_reference_smoke_shape_through_qlinear(dev):
     assert float(((C.float() - D) ** 2).mean() / D.var()) < 5e-2      # MXFP4 weights: ~1e-2 expected from the fp4 grid alone
 
 
-# launches of at most 48 64x64 tiles: split-K with the reduction inside the launch (split_tile_reduce: ticket per tile, the last
+# launches of at most 128 64x64 tiles (K <= 8192): split-K with the reduction inside the launch (split_tile_reduce: ticket per tile, the last
 # workgroup sums the partial sums in split order).  The DEFAULT plan is asserted, so a change of the rule cannot drop the case.
 IN_KERNEL_SPLIT = [(128, 1024, 4096, (2048, 128, 1920)), (100, 520, 2048, (1024, 256, 768)), (192, 1000, 5120, (0, 0, 5120)),
                    (65, 700, 2560, (2048, 0, 512)), (129, 1024, 4096, (4096, 0, 0))]
