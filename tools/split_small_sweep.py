@@ -8,9 +8,15 @@ from micromix_amd import _lib, mixedgemm
 lib = _lib.load(); dev = torch.device("cuda:0")
 g = torch.Generator().manual_seed(0)
 K, split = 4096, (2048, 128, 1920)
+SHAPES = ((128, 1024), (192, 1024), (256, 1024), (384, 1024), (512, 1024), (128, 2048), (256, 2048), (128, 4096), (256, 4096))
+if os.environ.get("SWEEP_SPLIT"):      # e.g. SWEEP_SPLIT=12288,1024,1024 SWEEP_SHAPES=128x4096,256x4096 (down_proj)
+    split = tuple(int(v) for v in os.environ["SWEEP_SPLIT"].split(","))
+    K = sum(split)
+if os.environ.get("SWEEP_SHAPES"):
+    SHAPES = tuple(tuple(int(v) for v in t.split("x")) for t in os.environ["SWEEP_SHAPES"].split(","))
 idx = torch.randperm(K, generator=g).to(torch.int16).to(dev)
 tag = os.environ.get("MICROMIX_SPLIT_SMALL", "rule")
-for M, N in ((128, 1024), (192, 1024), (256, 1024), (384, 1024), (512, 1024), (128, 2048), (256, 2048), (128, 4096), (256, 4096)):
+for M, N in SHAPES:
     w = (torch.randn((N, K), generator=g) * 0.02).to(torch.bfloat16).to(dev)
     x = torch.randn((M, K), generator=g).to(torch.bfloat16).to(dev)
     b = mixedgemm.reorder_quantize_w4(w, idx, *split); a = mixedgemm.reorder_quantize_x(x, idx, *split)
