@@ -277,8 +277,10 @@ static int plan_splits(int M, int N, const int K[3], bool w4, bool force, int fi
 //   32 tiles (k/v, N = 1024, M = 128)   11.3 / 10.7 /  9.5 /  8.9 us        64 tiles (N = 2048, M = 128)  12.7 / 11.2 / 11.5 / 15.2
 //   48 tiles (N = 1024, M = 192)        11.4 / 10.9 / 10.0 / 12.6           128 tiles (q/o, M = 128)      12.9 / 12.0 / 19.8 / 19.9
 //   64 tiles (N = 1024, M = 256)        11.2 / 11.2 / 10.8 / 13.9           256 tiles (q/o, M = 256)      12.8 / 22.7
-// More than one round of workgroups (tiles x splits > CUs) always loses.  Hence the rule below: six splits up to 32 tiles, four up
-// to 48, two up to 128, at least four slabs per split.  MICROMIX_SPLIT_SMALL=0 disables it, =<tile>:<S> (tile 33 = 64 x 64,
+// More than one round of workgroups (tiles x splits > CUs) always loses.  Two splits at 64 ... 128 tiles are a wash: an A/B on a second
+// box (alternating processes, profiles/notes_r03.md section 14) had the unsplit launch at 11.4 / 11.4 / 12.7 us and two splits at
+// 12.0 / 12.3 / 12.0 for q/o at M = 128.  Hence the rule below: six splits up to 32 tiles, four up to 48, none above, at least four
+// slabs per split.  MICROMIX_SPLIT_SMALL=0 disables it, =<tile>:<S> (tile 33 = 64 x 64,
 // 32 = 64 x 128; the latter never won) pins a plan (tools, tests); MM_SPLIT_K_ALWAYS relaxes the rule to "any split that fits one
 // round of workgroups".
 // ---------------------------------------------------------------------------------------------------------
@@ -316,11 +318,11 @@ static SmallSplit plan_small_split(int M, int N, const int K[3], bool force) {
         }
         return none;
     }
-    // measured rule (see above): six splits up to 32 tiles, four up to 48, two up to half a round of workgroups; never more than one
-    // round of workgroups, at least four slabs per split
+    // measured rule (see above): six splits up to 32 tiles, four up to 48, none above (two splits at 64 ... 128 tiles measured equal
+    // to the unsplit launch within the box-to-box spread); never more than one round of workgroups, at least four slabs per split
     // (longer K -- down_proj, 112 slabs -- stays with the two-launch split-K of the 128-row tiles, which cuts it into up to 16)
     if (total > 64) return none;
-    int S = t32n <= 32 ? 6 : t32n <= 48 ? 4 : 2 * t32n <= cus ? 2 : 0;
+    int S = t32n <= 32 ? 6 : t32n <= 48 ? 4 : 0;
     S = S > total / 4 ? total / 4 : S;
     S = (S == 5 || S == 3) ? S - 1 : S;
     return S >= 2 && t32n * S <= cus ? SmallSplit{33, S, t32n} : none;
