@@ -13,14 +13,22 @@
 // zero padded (the reference hard-codes that tree for T = 128 and is wrong for its other K; see the oracle's note).
 // fp32 divide and square root are the correctly rounded ones (the reference's rsqrt() approximation is not reproducible).
 //
-// Layout as reorder_quantize.hip: one workgroup strides over rows, thread t owns reordered group t, its 32 indices AND its
-// 32 gathered norm weights stay in registers for the whole launch, the row is staged in LDS by coalesced 16-byte loads.
+// Layout as reorder_quantize.hip: one workgroup strides over rows, thread t owns reordered group t, its 32 indices stay in
+// registers for the whole launch, the row is staged in LDS by coalesced 16-byte loads.
+//   K <= 8192 (rmsnorm_quantize_products_kernel): a thread keeps the norm weights of the four chunks it STAGES (natural order:
+//   four coalesced 16-byte loads) and stages the fp32 products x * w -- exact, two 8-bit significands -- so the gather reads the
+//   product with one ds_read_b32 and there is no gather of the weights at all.  The 32-bit row is laid out in two planes
+//   (elements 0-3 of every chunk, then elements 4-7) so that the staging writes stay whole 16-byte lanes side by side.  Every
+//   wave sums the partial sums by itself after ONE barrier (same tree, same order): two barriers per row instead of four.
+//   K > 8192 (rmsnorm_quantize_kernel): the 16-bit row and 32 gathered norm weights per thread in registers (the 32-bit row
+//   of K = 32768 would not fit the LDS).
 #include "mx_group_convert.h"
 #include "mx_kernels.h"
 
 namespace mm {
 
-template <int EL, bool INT_ROUND>
+// PRODUCTS: `row` holds fp32 products x * w at the byte offsets in `ix` (wg unused); else bf16 x at `ix` and the weights in wg
+template <int EL, bool INT_ROUND, bool PRODUCTS = false>
 __device__ __forceinline__ uint32_t rms_quantize_group(const uint8_t *__restrict__ row, const uint32_t (&ix)[16],
                                                        const uint32_t (&wg)[16], float rvar, uint8_t *__restrict__ out) {
     typedef float f2 __attribute__((ext_vector_type(2)));   // two-wide fp32 arithmetic (v_pk_mul_f32 / v_pk_add_f32)
@@ -29,11 +37,17 @@ __device__ __forceinline__ uint32_t rms_quantize_group(const uint8_t *__restrict
     const f2 rvar2 = {rvar, rvar};
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-        const f2 x = {bf16_bits_to_f32(*reinterpret_cast<const uint16_t *>(row + (ix[i] & 0xFFFFu))),
-                      bf16_bits_to_f32(*reinterpret_cast<const uint16_t *>(row + (ix[i] >> 16)))};
-        const f2 w = {bf16_bits_to_f32(wg[i] & 0xFFFFu), bf16_bits_to_f32(wg[i] >> 16)};
+        f2 xw;
+        if constexpr (PRODUCTS) {
+            xw = f2{*reinterpret_cast<const float *>(row + (ix[i] & 0xFFFFu)), *reinterpret_cast<const float *>(row + (ix[i] >> 16))};
+        } else {
+            const f2 x = {bf16_bits_to_f32(*reinterpret_cast<const uint16_t *>(row + (ix[i] & 0xFFFFu))),
+                          bf16_bits_to_f32(*reinterpret_cast<const uint16_t *>(row + (ix[i] >> 16)))};
+            const f2 w = {bf16_bits_to_f32(wg[i] & 0xFFFFu), bf16_bits_to_f32(wg[i] >> 16)};
+            xw = x * w;
+        }
         // (x * w) is exact in fp32 (two 8-bit significands); one rounding in the multiply by rvar, one to bf16
-        const f2 r = (x * w) * rvar2;
+        const f2 r = xw * rvar2;
         v[i] = pack_bf16x2(r[0], r[1]);
         const uint32_t mag = v[i] & 0x7FFF7FFFu;
         us2 m;
@@ -47,15 +61,18 @@ __device__ __forceinline__ uint32_t rms_quantize_group(const uint8_t *__restrict
         return 0u;
     }
     if constexpr (INT_ROUND) {
-        // round(v * 2^-e) half away from zero = trunc(t + copysign(0.5, t)).  The reference's clamp to +-FMAX cannot bite here:
-        // e is the smallest exponent with FMAX * 2^e >= amax, so |t| <= FMAX, an integer.
-        const float rs = __uint_as_float((uint32_t)(127 - e) << 23);  // 2^-e: v * 2^-e is exact
+        // round(v * 2^-e) half away from zero.  t = v * 2^-e is exact and has 8 significant bits, so t * (1 + 2^-10) is exact in
+        // fp32 too, lies strictly between t and the next point an 8-bit value could occupy, and is never a tie: rounding IT to
+        // nearest-even (v_rndne_f32) is rounding t half away from zero (a tie k + 0.5 moves off the tie, away from zero; a
+        // non-tie is at least one 8-bit step from the nearest tie, four times the nudge).  |t| >= 128 is an integer already and the
+        // nudge stays below 0.5.  The reference's clamp to +-FMAX cannot bite: e is the smallest exponent with
+        // FMAX * 2^e >= amax, so |t| <= FMAX, an integer.  (Was trunc(t + copysign(0.5, t)): 9 VALU operations per pair, now 6.)
+        const float rs = __uint_as_float(((uint32_t)(127 - e) << 23) | 0x2000u);  // 2^-e * (1 + 2^-10)
         const f2 rs2 = {rs, rs};
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            f2 t = f2{bf16_bits_to_f32(v[i] & 0xFFFFu), bf16_bits_to_f32(v[i] >> 16)} * rs2;
-            t = t + f2{__builtin_copysignf(0.5f, t[0]), __builtin_copysignf(0.5f, t[1])};
-            v[i] = pack_bf16x2(__builtin_truncf(t[0]), __builtin_truncf(t[1]));
+            const f2 t = f2{bf16_bits_to_f32(v[i] & 0xFFFFu), bf16_bits_to_f32(v[i] >> 16)} * rs2;
+            v[i] = pack_bf16x2(__builtin_rintf(t[0]), __builtin_rintf(t[1]));
         }
         convert_group<EL, true>(v, 1.0f, out);
     } else {
@@ -184,6 +201,127 @@ rmsnorm_quantize_kernel(const uint16_t *__restrict__ src, const uint16_t *__rest
     }
 }
 
+// K <= 8192: the row is staged as fp32 products x * w (see the header).  LDS: [plane A: K floats' first halves][plane B][P partial sums];
+// element c = 8q + e lives at byte (e < 4 ? 0 : 2K) + 16q + 4(e & 3), so chunk q's two halves are two conflict-free 16-byte writes.
+template <bool INT_ROUND>
+// (167 VGPRs: six workgroups per CU.  Bounding it to 128 for eight -- __launch_bounds__(256, 4) -- spills 38 registers: 14.4 -> 25.9 us.)
+__global__ void __launch_bounds__(256)
+rmsnorm_quantize_products_kernel(const uint16_t *__restrict__ src, const uint16_t *__restrict__ weight, float eps, int rows, int K,
+                                 const int16_t *__restrict__ idx, int KN, int KS, int KO, uint8_t *__restrict__ oN,
+                                 uint8_t *__restrict__ oS, uint8_t *__restrict__ oO, uint8_t *__restrict__ sfN,
+                                 uint8_t *__restrict__ sfS, uint8_t *__restrict__ sfO) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int T = K >> 5;
+    const int g = threadIdx.x;
+    const bool active = g < T;
+    const uint32_t planeB = (uint32_t)K * 2;
+    float *part = reinterpret_cast<float *>(smem + (size_t)K * 4);
+    int P = 64;
+    while (P < T) P <<= 1;
+
+    uint32_t ix[16];
+    const uint32_t none[16] = {};
+    uint4 wch[4];
+    if (active) {
+        const uint4 *p = reinterpret_cast<const uint4 *>(idx + (size_t)g * 32);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint4 q = p[i];
+            const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t c0 = w[k] & 0xFFFFu, c1 = w[k] >> 16;
+                const uint32_t b0 = ((c0 & 4u) ? planeB : 0u) + ((c0 >> 3) << 4) + ((c0 & 3u) << 2);
+                const uint32_t b1 = ((c1 & 4u) ? planeB : 0u) + ((c1 >> 3) << 4) + ((c1 & 3u) << 2);
+                ix[4 * i + k] = b0 | (b1 << 16);    // < 4K <= 32768: 16 bits each
+            }
+            wch[i] = reinterpret_cast<const uint4 *>(weight)[i * T + g];
+        }
+    }
+    const int gN = KN >> 5, gS = KS >> 5;
+    int seg, j, kseg;
+    if (g < gN) { seg = 0; j = g; kseg = KN; }
+    else if (g < gN + gS) { seg = 1; j = g - gN; kseg = KS; }
+    else { seg = 2; j = g - gN - gS; kseg = KO; }
+
+    uint4 stage[4];
+    auto fetch = [&](int r) {
+        if (active && r < rows) {
+            const uint4 *grow = reinterpret_cast<const uint4 *>(src + (size_t)r * K);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) stage[i] = grow[i * T + g];
+        }
+    };
+    auto stage_and_sum = [&]() -> float {
+        float sum = 0.0f;
+        if (active) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t x[4] = {stage[i].x, stage[i].y, stage[i].z, stage[i].w};
+                const uint32_t w[4] = {wch[i].x, wch[i].y, wch[i].z, wch[i].w};
+                float pr[8];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float a = bf16_bits_to_f32(x[k] & 0xFFFFu), b = bf16_bits_to_f32(x[k] >> 16);
+                    sum = __builtin_fmaf(a, a, sum);  // a*a is exact: the fused and the unfused forms round identically
+                    sum = __builtin_fmaf(b, b, sum);
+                    pr[2 * k] = a * bf16_bits_to_f32(w[k] & 0xFFFFu);
+                    pr[2 * k + 1] = b * bf16_bits_to_f32(w[k] >> 16);
+                }
+                const int q = i * T + g;
+                reinterpret_cast<float4 *>(smem)[q] = make_float4(pr[0], pr[1], pr[2], pr[3]);
+                reinterpret_cast<float4 *>(smem + planeB)[q] = make_float4(pr[4], pr[5], pr[6], pr[7]);
+            }
+        }
+        return sum;
+    };
+    fetch(blockIdx.x);
+    for (int r = blockIdx.x; r < rows; r += gridDim.x) {
+        const float sum = stage_and_sum();
+        fetch(r + gridDim.x);
+        part[g] = sum;              // threads T.. contribute the zero padding (P < 2 * blockDim.x)
+        if (g + (int)blockDim.x < P) part[g + blockDim.x] = 0.0f;
+        __syncthreads();
+        // every wave walks the halving tree s[t] += s[t + stride], stride = P/2 ... 1, by itself: lane l holds s[l + 64 j]
+        float rvar;
+        {
+            const int l = g & 63;
+            float v[4] = {part[l], 0.0f, 0.0f, 0.0f};
+            const int n0 = P >> 6;      // 1, 2 or 4
+            if (n0 > 1) v[1] = part[l + 64];
+            if (n0 > 2) { v[2] = part[l + 128]; v[3] = part[l + 192]; }
+            if (n0 > 2) { v[0] += v[2]; v[1] += v[3]; }
+            if (n0 > 1) v[0] += v[1];
+            float s = v[0];
+#pragma unroll
+            for (int stride = 32; stride >= 1; stride >>= 1) s += __shfl_down(s, stride, 64);
+            s = __shfl(s, 0, 64);
+            rvar = __fdiv_rn(1.0f, __fsqrt_rn(__fdiv_rn(s, (float)K) + eps));
+        }
+        if (active) {
+            const uint8_t *row = smem;
+            uint32_t byte;
+            uint8_t *sf;
+            if (seg == 0) {
+                byte = rms_quantize_group<EL_FP4, INT_ROUND, true>(row, ix, none, rvar, oN + (size_t)r * (KN >> 1) + j * 16);
+                sf = sfN;
+            } else if (seg == 1) {
+                byte = rms_quantize_group<EL_FP6, INT_ROUND, true>(row, ix, none, rvar, oS + (size_t)r * (KS / 4 * 3) + j * 24);
+                sf = sfS;
+            } else {
+                byte = rms_quantize_group<EL_FP8, INT_ROUND, true>(row, ix, none, rvar, oO + (size_t)r * KO + j * 32);
+                sf = sfO;
+            }
+            const uint32_t b1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)byte, 0x55, 0xF, 0xF, false);
+            const uint32_t b2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)byte, 0xAA, 0xF, 0xF, false);
+            const uint32_t b3 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)byte, 0xFF, 0xF, 0xF, false);
+            if ((g & 3) == 0)
+                *reinterpret_cast<uint32_t *>(sf + sf_offset(r, j, kseg)) = byte | (b1 << 8) | (b2 << 16) | (b3 << 24);
+        }
+        __syncthreads();  // the row and part[] are rewritten by the next iteration
+    }
+}
+
 hipError_t launch_rmsnorm_quantize(const void *src, const void *weight, float eps, int rows, int K, const int16_t *idx, int KN,
                                    int KS, int KO, bool integer_round, uint8_t *oN, uint8_t *oS, uint8_t *oO, uint8_t *sfN,
                                    uint8_t *sfS, uint8_t *sfO, hipStream_t stream) {
@@ -192,9 +330,10 @@ hipError_t launch_rmsnorm_quantize(const void *src, const void *weight, float ep
     const int threads = (T + 63) / 64 * 64;
     int P = 64;
     while (P < T) P <<= 1;
-    const size_t lds = (size_t)K * 2 + (size_t)(P > threads ? P : threads) * 4;
+    const bool products = threads <= 256;   // K <= 8192: the 32-bit product row (see the header)
+    const size_t lds = (size_t)K * (products ? 4 : 2) + (size_t)(P > threads ? P : threads) * 4;
     // 256 / 512 / 1024 threads: K <= 8192 / 16384 / 32768 (the 1024-thread variant is limited to 128 registers and spills a few)
-    auto kern = threads <= 256 ? (integer_round ? rmsnorm_quantize_kernel<true, 256> : rmsnorm_quantize_kernel<false, 256>)
+    auto kern = products ? (integer_round ? rmsnorm_quantize_products_kernel<true> : rmsnorm_quantize_products_kernel<false>)
               : threads <= 512 ? (integer_round ? rmsnorm_quantize_kernel<true, 512> : rmsnorm_quantize_kernel<false, 512>)
                                : (integer_round ? rmsnorm_quantize_kernel<true, 1024> : rmsnorm_quantize_kernel<false, 1024>);
     // K = 32768: 64 KiB of row + 4 KiB of partial sums, above the default 64 KiB limit of dynamic LDS

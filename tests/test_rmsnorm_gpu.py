@@ -26,6 +26,8 @@ def check_exact(got, want, rows, split, label):
 
 CASES = [(1, 128, (0, 128, 0)), (3, 384, (128, 128, 128)), (130, 4096, (2048, 1024, 1024)), (64, 4096, (0, 0, 4096)),
          (17, 5120, (4096, 512, 512)), (9, 3072, (1024, 1024, 1024)), (5, 3584, (3584, 0, 0)), (2, 14336, (7168, 512, 6656)),
+         (4, 8192, (4096, 2048, 2048)),       # the largest K of the 32-bit product row (256 threads, four partial sums per lane)
+         (3, 8320, (4096, 128, 4096)),        # the first K of the 16-bit row kernel
          (3, 20480, (8192, 4096, 8192)),      # K > 16384: the 1024-thread variant
          (3, 32768, (16384, 8192, 8192))]     # the largest K the int16 reorder index allows: 68 KiB of dynamic LDS
 
