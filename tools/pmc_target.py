@@ -1,12 +1,12 @@
 """Small fixed workload for the rocprofv3 passes: 10 x (reorder_quantize_x + matmul) per split on the 4096^3 bench shape, w4
 weights.  `python tools/pmc_target.py [KN,KS,KO[@MxNxK] ...]` (default: the bench split (0,0,4096); @MxNxK = another shape, e.g.
-12288,1024,1024@4096x4096x14336 for down_proj)."""
+12288,1024,1024@4096x4096x14336 for down_proj; M <= 8 also runs the fused decode kernel, mm_qlinear_decode, ten times)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 import bench
-from micromix_amd import mixedgemm
+from micromix_amd import _lib, mixedgemm
 dev = torch.device("cuda:0")
 args = sys.argv[1:] or [",".join(str(v) for v in bench.SPLIT)]
 for arg in args:
@@ -18,5 +18,12 @@ for arg in args:
     for _ in range(10):
         a = mixedgemm.reorder_quantize_x(x, idx, *split)
         d = mixedgemm.matmul(a[0], b[0], a[1], b[1], a[2], b[2], a[3], b[3], a[4], b[4], a[5], b[5])
+    if m <= 8:
+        lib = _lib.load()
+        od = torch.empty((m, n), dtype=torch.bfloat16, device=dev)
+        wp = [t.data_ptr() if t.numel() else None for t in b]
+        for _ in range(10):
+            assert lib.mm_qlinear_decode(x.data_ptr(), idx.data_ptr(), *wp, m, n, *split, 1, 0, None, od.data_ptr(),
+                                         torch.cuda.current_stream().cuda_stream) == 0
 torch.cuda.synchronize()
 print("ok")

@@ -41,7 +41,8 @@ if plain:
     lines.append(f"== bench.py JSON line of an unprofiled run of the same command on the same box ({CMD}) ==")
     lines.append(plain[-1].strip())
 traffic = None
-for name in ("fp8", "fp4", "mixed", "mixed3072", "down"):
+SMALL = ("few", "kv", "decode")     # launches that do not fill the chip with 256 eight-wave workgroups
+for name in ("fp8", "fp4", "mixed", "mixed3072", "down") + SMALL:
     d = os.path.join(root, "gpurun_out", f"pmc_{tag}_{name}")
     agg = collections.defaultdict(list)
     for f in glob.glob(d + "/*/*/*_counter_collection.csv"):
@@ -50,13 +51,27 @@ for name in ("fp8", "fp4", "mixed", "mixed3072", "down"):
     if not agg:
         continue
     head = open(os.path.join(d, "summary.txt")).readline().strip() if os.path.exists(os.path.join(d, "summary.txt")) else name
-    lines.append(f"== rocprofv3 --pmc passes -- python3 tools/pmc_target.py ({head}; 10 x quantize_x + matmul, 4096^3) ==")
+    lines.append(f"== rocprofv3 --pmc passes -- python3 tools/pmc_target.py ({head}; 10 x quantize_x + matmul" +
+                 (", 4096^3) ==" if name not in SMALL else "; M <= 8: + 10 x the fused decode kernel) =="))
     stat = {}
     for (k, c), v in sorted(agg.items()):
-        if "gemm" in k or "reorder" in k:
+        if "gemm" in k or "reorder" in k or "decode" in k:
             lines.append(f"{k:50s} {c:28s} n={len(v):3d} mean={sum(v)/len(v):.6g} min={min(v):.6g} max={max(v):.6g}")
-            stat[("gemm" if "gemm" in k else "quant", c)] = sum(v) / len(v)
+            stat[("gemm" if "gemm" in k else "decode" if "decode" in k else "quant", c)] = sum(v) / len(v)
     g = lambda c: stat.get(("gemm", c))
+    if name in SMALL:
+        for kind in ("gemm", "decode"):
+            h = lambda c: stat.get((kind, c))
+            if h("SQ_WAVE_CYCLES") and h("SQ_WAIT_ANY") is not None:
+                lines.append(f"derived ({kind} kernel): waves waiting (s_waitcnt/barrier) {h('SQ_WAIT_ANY')/h('SQ_WAVE_CYCLES'):.3f} of wave time, issue stalls "
+                             f"{h('SQ_WAIT_INST_ANY')/h('SQ_WAVE_CYCLES'):.3f}; matrix pipe busy {h('SQ_VALU_MFMA_BUSY_CYCLES'):.0f} SIMD-cycles of "
+                             f"{h('SQ_BUSY_CYCLES'):.0f} SQ-busy cycles")
+            if h("SQ_LDS_BANK_CONFLICT") is not None and h("SQ_LDS_IDX_ACTIVE"):
+                lines.append(f"derived ({kind} kernel): LDS bank-conflict cycles {h('SQ_LDS_BANK_CONFLICT'):.0f} = {h('SQ_LDS_BANK_CONFLICT')/h('SQ_LDS_IDX_ACTIVE'):.4f} of the LDS-active cycles")
+            if h("FETCH_SIZE") is not None and h("WRITE_SIZE") is not None:
+                lines.append(f"derived ({kind} kernel): HBM bytes per launch {int(2*h('FETCH_SIZE')*1024 + h('WRITE_SIZE')*1024)} (2 x FETCH_SIZE + WRITE_SIZE)"
+                             + (f", L2 hit rate {h('TCC_HIT_sum')/(h('TCC_HIT_sum')+h('TCC_MISS_sum')):.3f}" if h("TCC_HIT_sum") else ""))
+        continue
     if g("SQ_VALU_MFMA_BUSY_CYCLES") and g("SQ_WAVE_CYCLES"):
         # SQ_WAVE_CYCLES counts quad-cycles summed over the 2048 waves (two per SIMD); MFMA busy counts cycles summed over the 1024 SIMDs
         wave_cycles = g("SQ_WAVE_CYCLES") * 4 / 2048
