@@ -134,6 +134,16 @@ __device__ __forceinline__ void convert_group(const uint32_t (&v)[16], float sca
     }
 }
 
+// (reorder_quantize.hip, rmsnorm_quantize.hip)
+// The staged row is swizzled by 16-byte chunks: chunk q lives at q ^ ((q >> 4) & 3), i.e. inside every 1 KB the four 256-byte
+// (= 64-bank) rows are rotated against each other.  A random reorder index does not notice; an index that walks the columns in
+// order (the identity of mgemm/test.py, or a calibration that leaves whole runs in place) would otherwise send lane g to
+// byte 64 g + 2 i: four banks for 32 lanes, an eight-way conflict (21.2 us at 4096 x 4096 instead of 11.2; tools/time_quant.py
+// QUANT_IDX=identity); with the swizzle it is two-way.
+__device__ __forceinline__ int swizzle_chunk(int q) { return q ^ ((q >> 4) & 3); }
+// the same on two packed 16-bit byte offsets: bits 8-9 of each half are XORed into its bits 4-5
+__device__ __forceinline__ uint32_t swizzle_offsets(uint32_t two) { return two ^ ((two >> 4) & 0x00300030u); }
+
 // One 32-element group: gather (two bf16 per VGPR), block absmax, UE8M0 scale, convert, pack, store; returns the
 // scale byte.  `ix` holds BYTE offsets into the staged row (index << 1), two per register.
 // Conversion uses the CDNA4 MX converters (v_cvt_scalef32_pk_fp4_bf16 / _pk_fp8_bf16 / _pk32_bf6_bf16: dst =

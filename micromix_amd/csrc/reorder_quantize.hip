@@ -46,10 +46,10 @@ __device__ __forceinline__ void reorder_quantize_body(const uint16_t *__restrict
         for (int i = 0; i < 4; ++i) {
             const uint4 q = p[i];
             // keep BYTE offsets (index << 1; indices are < 32768 so each half stays within 16 bits)
-            ix[4 * i] = (q.x << 1) & 0xFFFEFFFEu;
-            ix[4 * i + 1] = (q.y << 1) & 0xFFFEFFFEu;
-            ix[4 * i + 2] = (q.z << 1) & 0xFFFEFFFEu;
-            ix[4 * i + 3] = (q.w << 1) & 0xFFFEFFFEu;
+            ix[4 * i] = swizzle_offsets((q.x << 1) & 0xFFFEFFFEu);
+            ix[4 * i + 1] = swizzle_offsets((q.y << 1) & 0xFFFEFFFEu);
+            ix[4 * i + 2] = swizzle_offsets((q.z << 1) & 0xFFFEFFFEu);
+            ix[4 * i + 3] = swizzle_offsets((q.w << 1) & 0xFFFEFFFEu);
         }
     }
     // Which segment this thread's group falls in (positions in reordered order).
@@ -77,7 +77,7 @@ __device__ __forceinline__ void reorder_quantize_body(const uint16_t *__restrict
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int c = threadIdx.x + i * blockDim.x;
-            if (c < nchunk) reinterpret_cast<uint4 *>(smem)[c] = stage[i];
+            if (c < nchunk) reinterpret_cast<uint4 *>(smem)[swizzle_chunk(c)] = stage[i];
         }
     }
     __syncthreads();
@@ -128,7 +128,7 @@ __device__ __forceinline__ void reorder_quantize_body(const uint16_t *__restrict
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int c = threadIdx.x + i * blockDim.x;
-                if (c < nchunk) reinterpret_cast<uint4 *>(smem)[c] = stage[i];
+                if (c < nchunk) reinterpret_cast<uint4 *>(smem)[swizzle_chunk(c)] = stage[i];
             }
         }
         __syncthreads();

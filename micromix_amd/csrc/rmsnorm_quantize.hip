@@ -102,7 +102,7 @@ rmsnorm_quantize_kernel(const uint16_t *__restrict__ src, const uint16_t *__rest
     if (active) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            reinterpret_cast<uint4 *>(smem)[i * T + g] = reinterpret_cast<const uint4 *>(weight)[i * T + g];
+            reinterpret_cast<uint4 *>(smem)[swizzle_chunk(i * T + g)] = reinterpret_cast<const uint4 *>(weight)[i * T + g];
     }
     __syncthreads();
     if (active) {
@@ -113,7 +113,8 @@ rmsnorm_quantize_kernel(const uint16_t *__restrict__ src, const uint16_t *__rest
             const uint32_t w[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const uint32_t b0 = (w[k] & 0xFFFFu) << 1, b1 = (w[k] >> 16) << 1;   // byte offsets into a staged [K] bf16 vector
+                const uint32_t both = swizzle_offsets((w[k] << 1) & 0xFFFEFFFEu);       // byte offsets into a staged (chunk-swizzled) [K] bf16 vector
+                const uint32_t b0 = both & 0xFFFFu, b1 = both >> 16;
                 ix[4 * i + k] = b0 | (b1 << 16);
                 wg[4 * i + k] = (uint32_t)*reinterpret_cast<const uint16_t *>(smem + b0) |
                                 ((uint32_t)*reinterpret_cast<const uint16_t *>(smem + b1) << 16);
@@ -142,7 +143,7 @@ rmsnorm_quantize_kernel(const uint16_t *__restrict__ src, const uint16_t *__rest
         if (active) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                reinterpret_cast<uint4 *>(smem)[i * T + g] = stage[i];
+                reinterpret_cast<uint4 *>(smem)[swizzle_chunk(i * T + g)] = stage[i];
                 const uint32_t w[4] = {stage[i].x, stage[i].y, stage[i].z, stage[i].w};
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -202,7 +203,8 @@ rmsnorm_quantize_kernel(const uint16_t *__restrict__ src, const uint16_t *__rest
 }
 
 // K <= 8192: the row is staged as fp32 products x * w (see the header).  LDS: [plane A: K floats' first halves][plane B][P partial sums];
-// element c = 8q + e lives at byte (e < 4 ? 0 : 2K) + 16q + 4(e & 3), so chunk q's two halves are two conflict-free 16-byte writes.
+// element c = 8q + e lives at byte (e < 4 ? 0 : 2K) + 16 q' + 4(e & 3), q' = swizzle_chunk(q) (mx_group_convert.h), so chunk q's two
+// halves are two conflict-free 16-byte writes.
 template <bool INT_ROUND>
 // (167 VGPRs: six workgroups per CU.  Bounding it to 128 for eight -- __launch_bounds__(256, 4) -- spills 38 registers: 14.4 -> 25.9 us.)
 __global__ void __launch_bounds__(256)
@@ -231,8 +233,8 @@ rmsnorm_quantize_products_kernel(const uint16_t *__restrict__ src, const uint16_
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const uint32_t c0 = w[k] & 0xFFFFu, c1 = w[k] >> 16;
-                const uint32_t b0 = ((c0 & 4u) ? planeB : 0u) + ((c0 >> 3) << 4) + ((c0 & 3u) << 2);
-                const uint32_t b1 = ((c1 & 4u) ? planeB : 0u) + ((c1 >> 3) << 4) + ((c1 & 3u) << 2);
+                const uint32_t b0 = ((c0 & 4u) ? planeB : 0u) + ((uint32_t)swizzle_chunk(c0 >> 3) << 4) + ((c0 & 3u) << 2);
+                const uint32_t b1 = ((c1 & 4u) ? planeB : 0u) + ((uint32_t)swizzle_chunk(c1 >> 3) << 4) + ((c1 & 3u) << 2);
                 ix[4 * i + k] = b0 | (b1 << 16);    // < 4K <= 32768: 16 bits each
             }
             wch[i] = reinterpret_cast<const uint4 *>(weight)[i * T + g];
@@ -268,7 +270,7 @@ rmsnorm_quantize_products_kernel(const uint16_t *__restrict__ src, const uint16_
                     pr[2 * k] = a * bf16_bits_to_f32(w[k] & 0xFFFFu);
                     pr[2 * k + 1] = b * bf16_bits_to_f32(w[k] >> 16);
                 }
-                const int q = i * T + g;
+                const int q = swizzle_chunk(i * T + g);
                 reinterpret_cast<float4 *>(smem)[q] = make_float4(pr[0], pr[1], pr[2], pr[3]);
                 reinterpret_cast<float4 *>(smem + planeB)[q] = make_float4(pr[4], pr[5], pr[6], pr[7]);
             }

@@ -8,6 +8,13 @@ from micromix_amd import _lib
 lib = _lib.load(); dev = torch.device("cuda:0")
 tag = os.path.basename(os.environ.get("MICROMIX_HIP_LIB", "default"))
 x, w, idx = [t.to(dev) for t in bench.synth_inputs()]
+if os.environ.get("QUANT_IDX") == "identity":      # the worst case: lane g reads element 32 g + i, a 64-byte stride = 4 banks for 32 lanes
+    idx = torch.arange(idx.numel(), dtype=torch.int16, device=dev)
+    tag += "/identity-index"
+if os.environ.get("QUANT_IDX") == "transpose":     # a conflict-free gather (group g, element i <- column 128 i + g): the bound for any fix of the bank conflicts
+    n = idx.numel()
+    idx = (torch.arange(32).view(1, 32) * (n // 32) + torch.arange(n // 32).view(-1, 1)).reshape(-1).to(torch.int16).to(dev)
+    tag += "/transpose-index"
 st = torch.cuda.current_stream().cuda_stream
 def run(src, rows, K, split, mode):
     KN, KS, KO = split
