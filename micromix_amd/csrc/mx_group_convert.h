@@ -10,10 +10,6 @@ typedef __bf16 bf32 __attribute__((ext_vector_type(32)));
 typedef short s2 __attribute__((ext_vector_type(2)));
 typedef unsigned u6 __attribute__((ext_vector_type(6)));
 
-// e == -127 (every element of the block is below FMAX * 2^-127): 2^127 times the value, integer encoder.
-// Inlined on purpose: as a __noinline__ call it cost 40 % of the kernel's time (15.3 vs 10.9 us at 4096 x 4096) although
-// it is practically never taken -- the call site pins the caller's registers.
-#define MM_TINY_INLINE __forceinline__
 // two fp32 -> packed bf16 pair {lo, hi}, round to nearest even (v_cvt_pk_bf16_f32)
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
     uint32_t r = 0;
@@ -23,69 +19,12 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
     return r;
 }
 
-// round to an integer, half away from zero (roundf), clamp to the format's range: the extra step of the reference's rmsnorm
-// quantizer (rmsnorm.cu:262-267), before its bf16 rounding.  x + copysign(0.5, x) is exact or, for |x| < 2^-17, rounds to
-// +-0.5 and truncates to 0 either way.
-template <int EL>
-__device__ __forceinline__ float integer_round_clamp(float x) {
-    constexpr float FM = EL == EL_FP4 ? 6.0f : (EL == EL_FP6 ? 28.0f : 448.0f);
-    const float r = __builtin_truncf(x + __builtin_copysignf(0.5f, x));
-    return __builtin_fminf(__builtin_fmaxf(r, -FM), FM);
-}
-template <int EL>
-__device__ __forceinline__ float integer_round_clamp_bf16(float x) {
-    return bf16_bits_to_f32(f32_to_bf16_bits(integer_round_clamp<EL>(x)));
-}
-
-template <int EL, bool INT_ROUND = false>
-__device__ MM_TINY_INLINE void quantize_group_tiny(const uint32_t *__restrict__ v, uint8_t *__restrict__ out) {
-    const float rs = __uint_as_float(254u << 23);  // 2^127
-    uint32_t c[32];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        float lo = bf16_bits_to_f32(v[i] & 0xFFFFu) * rs, hi = bf16_bits_to_f32(v[i] >> 16) * rs;
-        if constexpr (INT_ROUND) {
-            lo = integer_round_clamp_bf16<EL>(lo);
-            hi = integer_round_clamp_bf16<EL>(hi);
-        }
-        c[2 * i] = encode<EL>(lo);
-        c[2 * i + 1] = encode<EL>(hi);
-    }
-    if constexpr (EL == EL_FP8) {
-        uint32_t w[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) w[i] = c[4 * i] | (c[4 * i + 1] << 8) | (c[4 * i + 2] << 16) | (c[4 * i + 3] << 24);
-        uint4 *o = reinterpret_cast<uint4 *>(out);
-        o[0] = make_uint4(w[0], w[1], w[2], w[3]);
-        o[1] = make_uint4(w[4], w[5], w[6], w[7]);
-    } else if constexpr (EL == EL_FP4) {
-        uint32_t w[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            uint32_t x = 0;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) x |= (c[8 * i + k] & 0xFu) << (4 * k);  // element 2i in the low nibble
-            w[i] = x;
-        }
-        *reinterpret_cast<uint4 *>(out) = make_uint4(w[0], w[1], w[2], w[3]);
-    } else {
-        // dense little-endian 6-bit stream: 32 codes -> 192 bits -> three 64-bit words
-        unsigned long long w[3] = {0ull, 0ull, 0ull};
-#pragma unroll
-        for (int i = 0; i < 32; ++i) {
-            const int bit = 6 * i, word = bit >> 6, off = bit & 63;
-            const unsigned long long code = c[i] & 0x3Fu;
-            w[word] |= code << off;
-            if (off > 58) w[word + 1] |= code >> (64 - off);
-        }
-        unsigned long long *o = reinterpret_cast<unsigned long long *>(out);
-        o[0] = w[0];
-        o[1] = w[1];
-        o[2] = w[2];
-    }
-}
-
-// v[i] = {element 2i (low half), element 2i+1 (high half)} as bf16 bits; out = RNE(v / scale), scale a normal fp32 power of two.
+// v[i] = {element 2i (low half), element 2i+1 (high half)} as bf16 bits; out = RNE(v / scale), scale = the fp32 bit pattern
+// (127 + e) << 23.  The converters read the scale operand as E8M0 -- only its exponent field counts -- so the pattern 0 means
+// 2^-127, which no normal fp32 can express: a block whose absmax is below FMAX * 2^-127 (e = -127, scale byte 0) needs no path of
+// its own (it used to have one, 2^127 times the value through an integer encoder: 1500 instructions of cold code per format that
+// set the kernels' register count).  tools/probe_tiny_scale.py / tests/test_hw_gpu.py: scale patterns 0, 2^-127 and 2^-130 as
+// denormals all convert every in-range bf16, denormals included, exactly as the oracle's encoder of 2^127 * x does.
 // CDNA4 MX converters (v_cvt_scalef32_pk_fp4_bf16 / _pk_fp8_bf16 / _pk32_bf6_bf16: dst = RNE(src / scale), saturating) --
 // tests/test_hw_gpu.py checks them code-for-code against the oracle's encoders for every finite bf16.
 // GLOBAL_OUT: `out` is global memory (the stand-alone quantizers), so the fp4 codes may leave by a write-through store; the fused
@@ -149,11 +88,10 @@ __device__ __forceinline__ uint32_t swizzle_offsets(uint32_t two) { return two ^
 // Conversion uses the CDNA4 MX converters (v_cvt_scalef32_pk_fp4_bf16 / _pk_fp8_bf16 / _pk32_bf6_bf16: dst =
 // RNE(src / scale), saturating) -- tests/test_hw_gpu.py checks them code-for-code against the oracle's encoders for every
 // finite bf16, and tests/test_quantize_gpu.py checks the kernel's bytes.
-template <int EL, bool GLOBAL_OUT = false>
-__device__ __forceinline__ uint32_t quantize_group(const uint8_t *__restrict__ row, const uint32_t (&ix)[16],
-                                                   uint8_t *__restrict__ out) {
-    uint32_t v[16];  // v[i] = {element 2i (low half), element 2i+1 (high half)}
-    us2 amax2 = {0, 0};
+// gather_group is the same for every element format, so a wave whose lanes sit in different segments (an fp6 segment of four
+// groups next to 60 fp8 groups) runs it once; only finish_group -- scale, conversion, store -- diverges.
+__device__ __forceinline__ uint32_t gather_group(const uint8_t *__restrict__ row, const uint32_t (&ix)[16], uint32_t (&v)[16]) {
+    us2 amax2 = {0, 0};   // v[i] = {element 2i (low half), element 2i+1 (high half)}
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const uint32_t lo = *reinterpret_cast<const uint16_t *>(row + (ix[i] & 0xFFFFu));
@@ -164,14 +102,20 @@ __device__ __forceinline__ uint32_t quantize_group(const uint8_t *__restrict__ r
         __builtin_memcpy(&m, &mag, 4);
         amax2 = __builtin_elementwise_max(amax2, m);
     }
-    const uint32_t amax = amax2[0] > amax2[1] ? amax2[0] : amax2[1];
-    const int e = scale_exponent<EL>(amax << 16);
-    if (e == -127) {
-        quantize_group_tiny<EL>(v, out);
-        return 0u;
-    }
-    convert_group<EL, GLOBAL_OUT>(v, __uint_as_float((uint32_t)(127 + e) << 23), out);  // scale 2^e, a normal fp32
+    return amax2[0] > amax2[1] ? amax2[0] : amax2[1];   // bf16 magnitude bits of the block's absmax
+}
+template <int EL, bool GLOBAL_OUT = false>
+__device__ __forceinline__ uint32_t finish_group(const uint32_t (&v)[16], uint32_t amax, uint8_t *__restrict__ out) {
+    const int e = scale_exponent<EL>(amax << 16);   // -127 ... 127
+    convert_group<EL, GLOBAL_OUT>(v, __uint_as_float((uint32_t)(127 + e) << 23), out);  // scale 2^e as an E8M0 pattern (see convert_group)
     return (uint32_t)(e + 127);
+}
+template <int EL, bool GLOBAL_OUT = false>
+__device__ __forceinline__ uint32_t quantize_group(const uint8_t *__restrict__ row, const uint32_t (&ix)[16],
+                                                   uint8_t *__restrict__ out) {
+    uint32_t v[16];
+    const uint32_t amax = gather_group(row, ix, v);
+    return finish_group<EL, GLOBAL_OUT>(v, amax, out);
 }
 
 }  // namespace mm

@@ -38,6 +38,14 @@ __device__ __forceinline__ void reorder_quantize_body(const uint16_t *__restrict
     const int g = threadIdx.x;
     const bool active = g < G;
     const int nchunk = K >> 3;  // 16-byte chunks per row
+    // fp6 / fp8 codes are 24 / 32 bytes per lane: stored straight from the lanes, every store instruction covers 16 of each 32 bytes
+    // -- half lines, which cost 3 us of the 11.3 at 4096 x 4096 all-fp8 (measured: no stores 8.3 us; the first half only 11.9;
+    // the same bytes as fully covered write-through instructions 8.9; fully covered but plain 11.6).  So they go into an image of
+    // the row's [S | O] codes in LDS behind the staged row and leave after the barrier that ends the gather, 16 bytes per lane side
+    // by side, write-through: 11.3 -> 9.1 us.  (A layout of the image with the two halves of every group in separate planes, so
+    // that the lanes' writes are side by side too, changed nothing.)
+    const int bytesS = KS / 4 * 3, bytesO = KO;
+    uint8_t *image = smem + (size_t)K * 2;
 
     uint32_t ix[16];
     if (active) {
@@ -100,16 +108,18 @@ __device__ __forceinline__ void reorder_quantize_body(const uint16_t *__restrict
             const uint8_t *row = smem;
             uint32_t byte;
             uint8_t *sf;
+            uint32_t v[16];
+            const uint32_t amax = gather_group(row, ix, v);   // once per wave, whatever segments its lanes are in
             if (seg == 0) {
-                byte = quantize_group<EL_FP4, true>(row, ix, oN + (size_t)r * (KN >> 1) + j * 16);
+                byte = finish_group<EL_FP4, true>(v, amax, oN + (size_t)r * (KN >> 1) + j * 16);
                 sf = sfN;
             } else if (seg == 1) {
-                if constexpr (W4) byte = quantize_group<EL_FP4, true>(row, ix, oS + (size_t)r * (KS >> 1) + j * 16);
-                else byte = quantize_group<EL_FP6>(row, ix, oS + (size_t)r * (KS / 4 * 3) + j * 24);
+                if constexpr (W4) byte = finish_group<EL_FP4, true>(v, amax, oS + (size_t)r * (KS >> 1) + j * 16);
+                else byte = finish_group<EL_FP6>(v, amax, image + j * 24);                 // into the LDS image (see above)
                 sf = sfS;
             } else {
-                if constexpr (W4) byte = quantize_group<EL_FP4, true>(row, ix, oO + (size_t)r * (KO >> 1) + j * 16);
-                else byte = quantize_group<EL_FP8>(row, ix, oO + (size_t)r * KO + j * 32);
+                if constexpr (W4) byte = finish_group<EL_FP4, true>(v, amax, oO + (size_t)r * (KO >> 1) + j * 16);
+                else byte = finish_group<EL_FP8>(v, amax, image + bytesS + j * 32);
                 sf = sfO;
             }
             // the 4 block scales of one row and one 128-column slab are 4 consecutive bytes of the SF layout: gather them
@@ -124,6 +134,18 @@ __device__ __forceinline__ void reorder_quantize_body(const uint16_t *__restrict
         if (ck != nullptr && threadIdx.x == 0 && r == first_row) ck[2] = __builtin_amdgcn_s_memrealtime();
 #endif
         __syncthreads();
+        if constexpr (!W4) {
+            // the fp6 / fp8 codes of this row leave from the LDS image: 16 bytes per lane side by side, whole lines, write-through
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int off = (threadIdx.x + i * blockDim.x) * 16;
+                if (off < bytesS + bytesO) {
+                    const uint4 v = *reinterpret_cast<const uint4 *>(image + off);
+                    uint8_t *dst = off < bytesS ? oS + (size_t)r * bytesS + off : oO + (size_t)r * bytesO + (off - bytesS);
+                    store16<true>(dst, v.x, v.y, v.z, v.w);
+                }
+            }
+        }
         if (rn < rows) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -170,9 +192,13 @@ hipError_t launch_reorder_quantize(const void *src, int rows, int K, const int16
     const int G = (KN + KS + KO) / 32;
     const int stagers = K / 32;  // a row of K bf16 is staged as K/8 16-byte chunks, at most 4 per thread
     const int threads = ((G > stagers ? G : stagers) + 63) / 64 * 64;
-    const size_t lds = (size_t)K * 2;
+    const size_t lds = (size_t)K * 2 + (w4 ? 0 : (size_t)KS / 4 * 3 + KO);   // the staged row + the image of its fp6 / fp8 codes
     auto kern = threads <= 256 ? (w4 ? reorder_quantize_kernel<true, 256> : reorder_quantize_kernel<false, 256>)
                                : (w4 ? reorder_quantize_kernel<true, 1024> : reorder_quantize_kernel<false, 1024>);
+    // K > 21845: the row and the image together pass the default 64 KiB limit of dynamic LDS (at most 96 KiB, K = 32768)
+    static DynamicLdsOnce big_lds;
+    if (lds > 48 * 1024)
+        if (hipError_t e = big_lds.ensure(reinterpret_cast<const void *>(reorder_quantize_kernel<false, 1024>), 96 * 1024); e != hipSuccess) return e;
     // one resident wave of workgroups (no tail), each striding over the rows
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kern), threads, lds) != hipSuccess ||
@@ -194,9 +220,12 @@ hipError_t launch_reorder_quantize_grouped(const GroupedQuantArgs &ga, int max_r
     if (ga.ngroups < 1 || ga.ngroups > MM_MAX_GROUPS || max_rows < 1) return hipErrorInvalidValue;
     const int G = (ga.KN + ga.KS + ga.KO) / 32, stagers = ga.K / 32;
     const int threads = ((G > stagers ? G : stagers) + 63) / 64 * 64;
-    const size_t lds = (size_t)ga.K * 2;
+    const size_t lds = (size_t)ga.K * 2 + (w4 ? 0 : (size_t)ga.KS / 4 * 3 + ga.KO);
     auto kern = threads <= 256 ? (w4 ? reorder_quantize_grouped_kernel<true, 256> : reorder_quantize_grouped_kernel<false, 256>)
                                : (w4 ? reorder_quantize_grouped_kernel<true, 1024> : reorder_quantize_grouped_kernel<false, 1024>);
+    static DynamicLdsOnce big_lds;
+    if (lds > 48 * 1024)
+        if (hipError_t e = big_lds.ensure(reinterpret_cast<const void *>(reorder_quantize_grouped_kernel<false, 1024>), 96 * 1024); e != hipSuccess) return e;
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kern), threads, lds) != hipSuccess ||
         per_cu < 1)

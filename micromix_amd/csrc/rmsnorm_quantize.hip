@@ -56,10 +56,8 @@ __device__ __forceinline__ uint32_t rms_quantize_group(const uint8_t *__restrict
     }
     const uint32_t amax = amax2[0] > amax2[1] ? amax2[0] : amax2[1];
     const int e = scale_exponent<EL>(amax << 16);
-    if (e == -127) {
-        quantize_group_tiny<EL, INT_ROUND>(v, out);
-        return 0u;
-    }
+    // (e = -127, a block below FMAX * 2^-127, takes the same path: 2^127 * (1 + 2^-10) is a normal fp32, and the converters read the
+    // scale pattern 0 as 2^-127 -- see convert_group)
     if constexpr (INT_ROUND) {
         // round(v * 2^-e) half away from zero.  t = v * 2^-e is exact and has 8 significant bits, so t * (1 + 2^-10) is exact in
         // fp32 too, lies strictly between t and the next point an 8-bit value could occupy, and is never a tie: rounding IT to
