@@ -50,6 +50,16 @@ __device__ __forceinline__ int scale_exponent(uint32_t amax_bits) {
     return amax_bits == 0 ? -1 : e;
 }
 
+// the same with the format's FMAX = (1 + fmax_mant / 2^23) * 2^fmax_exp as run-time values (lanes of one wave in different segments)
+__device__ __forceinline__ int scale_exponent_rt(uint32_t amax_bits, int fmax_exp, uint32_t fmax_mant) {
+    const int exp = (int)(amax_bits >> 23);
+    const uint32_t mant = amax_bits & 0x7FFFFFu;
+    int e = exp - 127 - fmax_exp + (mant > fmax_mant ? 1 : 0);
+    e = exp == 0 ? -127 : e;
+    e = e < -127 ? -127 : (e > 127 ? 127 : e);
+    return amax_bits == 0 ? -1 : e;
+}
+
 // fp32 -> element code, round-to-nearest-even, saturating, sign kept on zero.
 template <int EL>
 __device__ __forceinline__ uint32_t encode(float x) {

@@ -38,12 +38,7 @@ __device__ __forceinline__ void reorder_quantize_body(const uint16_t *__restrict
     const int g = threadIdx.x;
     const bool active = g < G;
     const int nchunk = K >> 3;  // 16-byte chunks per row
-    // fp6 / fp8 codes are 24 / 32 bytes per lane: stored straight from the lanes, every store instruction covers 16 of each 32 bytes
-    // -- half lines, which cost 3 us of the 11.3 at 4096 x 4096 all-fp8 (measured: no stores 8.3 us; the first half only 11.9;
-    // the same bytes as fully covered write-through instructions 8.9; fully covered but plain 11.6).  So they go into an image of
-    // the row's [S | O] codes in LDS behind the staged row and leave after the barrier that ends the gather, 16 bytes per lane side
-    // by side, write-through: 11.3 -> 9.1 us.  (A layout of the image with the two halves of every group in separate planes, so
-    // that the lanes' writes are side by side too, changed nothing.)
+    // fp6 / fp8 codes go through an image of the row's [S | O] codes behind the staged row (store_code_image, mx_group_convert.h): 11.3 -> 9.3 us
     const int bytesS = KS / 4 * 3, bytesO = KO;
     uint8_t *image = smem + (size_t)K * 2;
 
@@ -134,18 +129,7 @@ __device__ __forceinline__ void reorder_quantize_body(const uint16_t *__restrict
         if (ck != nullptr && threadIdx.x == 0 && r == first_row) ck[2] = __builtin_amdgcn_s_memrealtime();
 #endif
         __syncthreads();
-        if constexpr (!W4) {
-            // the fp6 / fp8 codes of this row leave from the LDS image: 16 bytes per lane side by side, whole lines, write-through
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int off = (threadIdx.x + i * blockDim.x) * 16;
-                if (off < bytesS + bytesO) {
-                    const uint4 v = *reinterpret_cast<const uint4 *>(image + off);
-                    uint8_t *dst = off < bytesS ? oS + (size_t)r * bytesS + off : oO + (size_t)r * bytesO + (off - bytesS);
-                    store16<true>(dst, v.x, v.y, v.z, v.w);
-                }
-            }
-        }
+        if constexpr (!W4) store_code_image(image, bytesS, bytesO, oS, oO, r);
         if (rn < rows) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {

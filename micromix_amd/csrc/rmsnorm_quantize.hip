@@ -27,12 +27,14 @@
 
 namespace mm {
 
-// PRODUCTS: `row` holds fp32 products x * w at the byte offsets in `ix` (wg unused); else bf16 x at `ix` and the weights in wg
-template <int EL, bool INT_ROUND, bool PRODUCTS = false>
-__device__ __forceinline__ uint32_t rms_quantize_group(const uint8_t *__restrict__ row, const uint32_t (&ix)[16],
-                                                       const uint32_t (&wg)[16], float rvar, uint8_t *__restrict__ out) {
+// One group in three steps, the first two the same for every element format, so that a wave whose lanes sit in different
+// segments runs them once (only the conversion diverges):
+//   rms_gather: v = bf16((x * w) * rvar) for the group's 32 columns, returns the absmax's bf16 magnitude bits.
+//     PRODUCTS: `row` holds fp32 products x * w at the byte offsets in `ix` (wg unused); else bf16 x at `ix` and the weights in wg
+template <bool PRODUCTS>
+__device__ __forceinline__ uint32_t rms_gather(const uint8_t *__restrict__ row, const uint32_t (&ix)[16], const uint32_t (&wg)[16],
+                                               float rvar, uint32_t (&v)[16]) {
     typedef float f2 __attribute__((ext_vector_type(2)));   // two-wide fp32 arithmetic (v_pk_mul_f32 / v_pk_add_f32)
-    uint32_t v[16];
     us2 amax2 = {0, 0};
     const f2 rvar2 = {rvar, rvar};
 #pragma unroll
@@ -54,17 +56,23 @@ __device__ __forceinline__ uint32_t rms_quantize_group(const uint8_t *__restrict
         __builtin_memcpy(&m, &mag, 4);
         amax2 = __builtin_elementwise_max(amax2, m);
     }
-    const uint32_t amax = amax2[0] > amax2[1] ? amax2[0] : amax2[1];
-    const int e = scale_exponent<EL>(amax << 16);
-    // (e = -127, a block below FMAX * 2^-127, takes the same path: 2^127 * (1 + 2^-10) is a normal fp32, and the converters read the
-    // scale pattern 0 as 2^-127 -- see convert_group)
+    return amax2[0] > amax2[1] ? amax2[0] : amax2[1];
+}
+//   rms_scale: the block's exponent e for the lane's format (FMAX given by fexp / fmant); with INT_ROUND v becomes
+//     round(v * 2^-e), half away from zero, and the conversion's scale 1; returns the scale pattern for convert_group.
+//     (e = -127, a block below FMAX * 2^-127, is no special case: 2^127 * (1 + 2^-10) is a normal fp32, and the converters read the
+//     scale pattern 0 as 2^-127 -- see convert_group.)
+template <bool INT_ROUND>
+__device__ __forceinline__ float rms_scale(uint32_t (&v)[16], uint32_t amax, int fexp, uint32_t fmant, int &e) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    e = scale_exponent_rt(amax << 16, fexp, fmant);
     if constexpr (INT_ROUND) {
-        // round(v * 2^-e) half away from zero.  t = v * 2^-e is exact and has 8 significant bits, so t * (1 + 2^-10) is exact in
-        // fp32 too, lies strictly between t and the next point an 8-bit value could occupy, and is never a tie: rounding IT to
-        // nearest-even (v_rndne_f32) is rounding t half away from zero (a tie k + 0.5 moves off the tie, away from zero; a
-        // non-tie is at least one 8-bit step from the nearest tie, four times the nudge).  |t| >= 128 is an integer already and the
-        // nudge stays below 0.5.  The reference's clamp to +-FMAX cannot bite: e is the smallest exponent with
-        // FMAX * 2^e >= amax, so |t| <= FMAX, an integer.  (Was trunc(t + copysign(0.5, t)): 9 VALU operations per pair, now 6.)
+        // t = v * 2^-e is exact and has 8 significant bits, so t * (1 + 2^-10) is exact in fp32 too, lies strictly between t and the
+        // next point an 8-bit value could occupy, and is never a tie: rounding IT to nearest-even (v_rndne_f32) is rounding t half
+        // away from zero (a tie k + 0.5 moves off the tie, away from zero; a non-tie is at least one 8-bit step from the nearest
+        // tie, four times the nudge).  |t| >= 128 is an integer already and the nudge stays below 0.5.  The reference's clamp to
+        // +-FMAX cannot bite: e is the smallest exponent with FMAX * 2^e >= amax, so |t| <= FMAX, an integer.
+        // (Was trunc(t + copysign(0.5, t)): 9 VALU operations per pair, now 6.)
         const float rs = __uint_as_float(((uint32_t)(127 - e) << 23) | 0x2000u);  // 2^-e * (1 + 2^-10)
         const f2 rs2 = {rs, rs};
 #pragma unroll
@@ -72,10 +80,25 @@ __device__ __forceinline__ uint32_t rms_quantize_group(const uint8_t *__restrict
             const f2 t = f2{bf16_bits_to_f32(v[i] & 0xFFFFu), bf16_bits_to_f32(v[i] >> 16)} * rs2;
             v[i] = pack_bf16x2(__builtin_rintf(t[0]), __builtin_rintf(t[1]));
         }
-        convert_group<EL, true>(v, 1.0f, out);
+        return 1.0f;
     } else {
-        convert_group<EL, true>(v, __uint_as_float((uint32_t)(127 + e) << 23), out);
+        return __uint_as_float((uint32_t)(127 + e) << 23);
     }
+}
+//   then convert_group<EL> into global memory (fp4: 16 bytes per lane, whole lines as they are) or into the LDS image of the row's
+//   fp6 / fp8 codes (store_code_image, mx_group_convert.h).
+template <bool INT_ROUND, bool PRODUCTS>
+__device__ __forceinline__ uint32_t rms_group(const uint8_t *__restrict__ row, const uint32_t (&ix)[16], const uint32_t (&wg)[16],
+                                              float rvar, int seg, int j, int r, int KN, uint8_t *oN, uint8_t *image, int bytesS) {
+    uint32_t v[16];
+    const uint32_t amax = rms_gather<PRODUCTS>(row, ix, wg, rvar, v);
+    const int fexp = seg == 0 ? ElemTraits<EL_FP4>::FMAX_EXP : seg == 1 ? ElemTraits<EL_FP6>::FMAX_EXP : ElemTraits<EL_FP8>::FMAX_EXP;
+    const uint32_t fmant = seg == 0 ? ElemTraits<EL_FP4>::FMAX_MANT : seg == 1 ? ElemTraits<EL_FP6>::FMAX_MANT : ElemTraits<EL_FP8>::FMAX_MANT;
+    int e;
+    const float scale = rms_scale<INT_ROUND>(v, amax, fexp, fmant, e);
+    if (seg == 0) convert_group<EL_FP4, true>(v, scale, oN + (size_t)r * (KN >> 1) + j * 16);
+    else if (seg == 1) convert_group<EL_FP6>(v, scale, image + j * 24);
+    else convert_group<EL_FP8>(v, scale, image + bytesS + j * 32);
     return (uint32_t)(e + 127);
 }
 
@@ -92,6 +115,8 @@ rmsnorm_quantize_kernel(const uint16_t *__restrict__ src, const uint16_t *__rest
     float *part = reinterpret_cast<float *>(smem + (size_t)K * 2);
     int P = 64;
     while (P < T) P <<= 1;
+    const int bytesS = KS / 4 * 3;
+    uint8_t *image = smem + (size_t)K * 2 + (size_t)(P > (int)blockDim.x ? P : (int)blockDim.x) * 4;   // [row][partial sums][image of the S | O codes]
 
     // the norm weights of this thread's 32 columns: the weight vector is staged in LDS (coalesced) and gathered from there
     // with the same byte offsets as the row (32 scattered 2-byte global loads per thread cost more than the two rows a
@@ -180,16 +205,8 @@ rmsnorm_quantize_kernel(const uint16_t *__restrict__ src, const uint16_t *__rest
             const uint8_t *row = smem;
             uint32_t byte;
             uint8_t *sf;
-            if (seg == 0) {
-                byte = rms_quantize_group<EL_FP4, INT_ROUND>(row, ix, wg, rvar, oN + (size_t)r * (KN >> 1) + j * 16);
-                sf = sfN;
-            } else if (seg == 1) {
-                byte = rms_quantize_group<EL_FP6, INT_ROUND>(row, ix, wg, rvar, oS + (size_t)r * (KS / 4 * 3) + j * 24);
-                sf = sfS;
-            } else {
-                byte = rms_quantize_group<EL_FP8, INT_ROUND>(row, ix, wg, rvar, oO + (size_t)r * KO + j * 32);
-                sf = sfO;
-            }
+            byte = rms_group<INT_ROUND, false>(row, ix, wg, rvar, seg, j, r, KN, oN, image, bytesS);
+            sf = seg == 0 ? sfN : seg == 1 ? sfS : sfO;
             const uint32_t b1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)byte, 0x55, 0xF, 0xF, false);
             const uint32_t b2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)byte, 0xAA, 0xF, 0xF, false);
             const uint32_t b3 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)byte, 0xFF, 0xF, 0xF, false);
@@ -197,6 +214,7 @@ rmsnorm_quantize_kernel(const uint16_t *__restrict__ src, const uint16_t *__rest
                 *reinterpret_cast<uint32_t *>(sf + sf_offset(r, j, kseg)) = byte | (b1 << 8) | (b2 << 16) | (b3 << 24);
         }
         __syncthreads();  // the row and part[] are rewritten by the next iteration
+        store_code_image(image, bytesS, KO, oS, oO, r);   // (read here, rewritten only after the next iteration's first barrier)
     }
 }
 
@@ -218,6 +236,8 @@ rmsnorm_quantize_products_kernel(const uint16_t *__restrict__ src, const uint16_
     float *part = reinterpret_cast<float *>(smem + (size_t)K * 4);
     int P = 64;
     while (P < T) P <<= 1;
+    const int bytesS = KS / 4 * 3;
+    uint8_t *image = smem + (size_t)K * 4 + (size_t)(P > (int)blockDim.x ? P : (int)blockDim.x) * 4;   // [planes][partial sums][image of the S | O codes]
 
     uint32_t ix[16];
     const uint32_t none[16] = {};
@@ -302,16 +322,8 @@ rmsnorm_quantize_products_kernel(const uint16_t *__restrict__ src, const uint16_
             const uint8_t *row = smem;
             uint32_t byte;
             uint8_t *sf;
-            if (seg == 0) {
-                byte = rms_quantize_group<EL_FP4, INT_ROUND, true>(row, ix, none, rvar, oN + (size_t)r * (KN >> 1) + j * 16);
-                sf = sfN;
-            } else if (seg == 1) {
-                byte = rms_quantize_group<EL_FP6, INT_ROUND, true>(row, ix, none, rvar, oS + (size_t)r * (KS / 4 * 3) + j * 24);
-                sf = sfS;
-            } else {
-                byte = rms_quantize_group<EL_FP8, INT_ROUND, true>(row, ix, none, rvar, oO + (size_t)r * KO + j * 32);
-                sf = sfO;
-            }
+            byte = rms_group<INT_ROUND, true>(row, ix, none, rvar, seg, j, r, KN, oN, image, bytesS);
+            sf = seg == 0 ? sfN : seg == 1 ? sfS : sfO;
             const uint32_t b1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)byte, 0x55, 0xF, 0xF, false);
             const uint32_t b2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)byte, 0xAA, 0xF, 0xF, false);
             const uint32_t b3 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)byte, 0xFF, 0xF, 0xF, false);
@@ -319,6 +331,7 @@ rmsnorm_quantize_products_kernel(const uint16_t *__restrict__ src, const uint16_
                 *reinterpret_cast<uint32_t *>(sf + sf_offset(r, j, kseg)) = byte | (b1 << 8) | (b2 << 16) | (b3 << 24);
         }
         __syncthreads();  // the row and part[] are rewritten by the next iteration
+        store_code_image(image, bytesS, KO, oS, oO, r);   // (read here, rewritten only after the next iteration's first barrier)
     }
 }
 
@@ -331,16 +344,16 @@ hipError_t launch_rmsnorm_quantize(const void *src, const void *weight, float ep
     int P = 64;
     while (P < T) P <<= 1;
     const bool products = threads <= 256;   // K <= 8192: the 32-bit product row (see the header)
-    const size_t lds = (size_t)K * (products ? 4 : 2) + (size_t)(P > threads ? P : threads) * 4;
+    const size_t lds = (size_t)K * (products ? 4 : 2) + (size_t)(P > threads ? P : threads) * 4 + (size_t)KS / 4 * 3 + KO;
     // 256 / 512 / 1024 threads: K <= 8192 / 16384 / 32768 (the 1024-thread variant is limited to 128 registers and spills a few)
     auto kern = products ? (integer_round ? rmsnorm_quantize_products_kernel<true> : rmsnorm_quantize_products_kernel<false>)
               : threads <= 512 ? (integer_round ? rmsnorm_quantize_kernel<true, 512> : rmsnorm_quantize_kernel<false, 512>)
                                : (integer_round ? rmsnorm_quantize_kernel<true, 1024> : rmsnorm_quantize_kernel<false, 1024>);
-    // K = 32768: 64 KiB of row + 4 KiB of partial sums, above the default 64 KiB limit of dynamic LDS
+    // K > ~21000: row + partial sums + the image of the fp6 / fp8 codes pass the default 64 KiB limit of dynamic LDS (K = 32768: 100 KiB)
     static DynamicLdsOnce attr[6];
     if (lds > 48 * 1024) {
         const int which = (threads <= 256 ? 0 : threads <= 512 ? 1 : 2) * 2 + (integer_round ? 1 : 0);
-        if (hipError_t e = attr[which].ensure(reinterpret_cast<const void *>(kern), 72 * 1024); e != hipSuccess) return e;
+        if (hipError_t e = attr[which].ensure(reinterpret_cast<const void *>(kern), 104 * 1024); e != hipSuccess) return e;
     }
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kern), threads, lds) != hipSuccess ||
