@@ -8,8 +8,8 @@ lib = _lib.load(); dev = torch.device("cuda:0")
 g = torch.Generator().manual_seed(0)
 st = torch.cuda.current_stream().cuda_stream
 pp = lambda t: t.data_ptr() if t.numel() else None
-K, split = 14336, (7168, 512, 6656)
-for M in (16, 256, 2048, 4096):
+K = 14336
+for M, split in ((256, (7168, 512, 6656)), (4096, (7168, 512, 6656)), (4096, (12288, 1024, 1024)), (4096, (0, 0, 14336)), (4096, (14336, 0, 0))):
     a = torch.randn((M, K), generator=g).to(torch.bfloat16).to(dev)
     b = torch.randn((M, K), generator=g).to(torch.bfloat16).to(dev)
     o = mixedgemm.activate_quantize_x(a, b, *split)
@@ -22,4 +22,4 @@ for M in (16, 256, 2048, 4096):
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 10
     byts = 2 * M * K * 2 + M * (split[0] // 2 + split[1] * 3 // 4 + split[2]) + M * K // 32
-    print(f"activate_quantize_x M={M:5d} K={K}: {us:7.1f} us  {byts / us / 1e6:5.2f} TB/s", flush=True)
+    print(f"{os.path.basename(os.environ.get('MICROMIX_HIP_LIB', 'default')):12s} activate_quantize_x M={M:5d} K={K} {split}: {us:7.1f} us  {byts / us / 1e6:5.2f} TB/s", flush=True)
