@@ -11,7 +11,10 @@
 // elements i*K/4 + 8t + j, i = 0..3, j = 0..7, one after the other -- these are exactly the four 16-byte chunks the thread
 // stages into LDS -- and the T partial sums meet in the halving tree s[t] += s[t + stride] over the next power of two,
 // zero padded (the reference hard-codes that tree for T = 128 and is wrong for its other K; see the oracle's note).
-// fp32 divide and square root are the correctly rounded ones (the reference's rsqrt() approximation is not reproducible).
+// fp32 divide and square root are the correctly rounded ones (the reference's rsqrt() approximation is not reproducible):
+// __fdiv_rn and __builtin_sqrtf.  NOT __fsqrt_rn, which on this toolchain is the native v_sqrt_f32 -- one ulp off for 15 % of
+// arguments (tools/probe_rvar.hip); rounds 1-2 used it, and about one row in 7000 then had an element one code off against the
+// oracle (found by tests/quant_stress.py in round 3; the fixed test cases had happened to miss it).
 //
 // Layout as reorder_quantize.hip: one workgroup strides over rows, thread t owns reordered group t, its 32 indices stay in
 // registers for the whole launch, the row is staged in LDS by coalesced 16-byte loads.
@@ -197,7 +200,7 @@ rmsnorm_quantize_kernel(const uint16_t *__restrict__ src, const uint16_t *__rest
             float s = part[g];
 #pragma unroll
             for (int stride = 32; stride >= 1; stride >>= 1) s += __shfl_down(s, stride, 64);
-            if (g == 0) part[0] = __fdiv_rn(1.0f, __fsqrt_rn(__fdiv_rn(s, (float)K) + eps));
+            if (g == 0) part[0] = __fdiv_rn(1.0f, __builtin_sqrtf(__fdiv_rn(s, (float)K) + eps));
         }
         __syncthreads();
         const float rvar = part[0];
@@ -316,7 +319,7 @@ rmsnorm_quantize_products_kernel(const uint16_t *__restrict__ src, const uint16_
 #pragma unroll
             for (int stride = 32; stride >= 1; stride >>= 1) s += __shfl_down(s, stride, 64);
             s = __shfl(s, 0, 64);
-            rvar = __fdiv_rn(1.0f, __fsqrt_rn(__fdiv_rn(s, (float)K) + eps));
+            rvar = __fdiv_rn(1.0f, __builtin_sqrtf(__fdiv_rn(s, (float)K) + eps));
         }
         if (active) {
             const uint8_t *row = smem;

@@ -12,10 +12,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("tool,seconds", [("stress.py", 20), ("stress_grouped.py", 12), ("stress_split.py", 12)])
+@pytest.mark.parametrize("tool,seconds", [("tools/stress.py", 20), ("tools/stress_grouped.py", 12), ("tools/stress_split.py", 12),
+                                          ("tests/quant_stress.py", 25)])   # the last: every quantizer kernel against the oracle, byte for byte
 def test_seeded_stress_slice(dev, tool, seconds):
     env = dict(os.environ, STRESS_SEED="12345")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool), str(seconds)], env=env, capture_output=True, text=True,
+    r = subprocess.run([sys.executable, os.path.join(ROOT, tool), str(seconds)], env=env, capture_output=True, text=True,
                        timeout=300)
     tail = "\n".join((r.stdout + r.stderr).strip().splitlines()[-8:])
     assert r.returncode == 0, tail
