@@ -1,6 +1,8 @@
 """Seeded random shapes / splits / weight modes / rounding modes / bias through mixedgemm.matmul against the oracle on a row sample:
 the deterministic shape lists of test_matmul_gpu.py pick the dispatch boundaries, this picks everything else at random (the
 randomised tools/stress.py compares paths with each other; only tests may ask the oracle)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -27,7 +29,8 @@ def _cases(n=48, seed=20260):
     return out
 
 
-CASES = _cases()
+# RANDOM_ORACLE_CASES / RANDOM_ORACLE_SEED: longer one-off runs (1500 cases of another seed take about five minutes)
+CASES = _cases(int(os.environ.get("RANDOM_ORACLE_CASES", "48")), int(os.environ.get("RANDOM_ORACLE_SEED", "20260")))
 
 
 @pytest.mark.parametrize("m,n,split,wmode,rounding,with_bias", CASES,
