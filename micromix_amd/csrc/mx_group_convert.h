@@ -23,7 +23,7 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 // (127 + e) << 23.  The converters read the scale operand as E8M0 -- only its exponent field counts -- so the pattern 0 means
 // 2^-127, which no normal fp32 can express: a block whose absmax is below FMAX * 2^-127 (e = -127, scale byte 0) needs no path of
 // its own (it used to have one, 2^127 times the value through an integer encoder: 1500 instructions of cold code per format that
-// set the kernels' register count).  tools/probe_tiny_scale.py / tests/test_hw_gpu.py: scale patterns 0, 2^-127 and 2^-130 as
+// set the kernels' register count).  tests/probe_tiny_scale.py / tests/test_hw_gpu.py: scale patterns 0, 2^-127 and 2^-130 as
 // denormals all convert every in-range bf16, denormals included, exactly as the oracle's encoder of 2^127 * x does.
 // CDNA4 MX converters (v_cvt_scalef32_pk_fp4_bf16 / _pk_fp8_bf16 / _pk32_bf6_bf16: dst = RNE(src / scale), saturating) --
 // tests/test_hw_gpu.py checks them code-for-code against the oracle's encoders for every finite bf16.

@@ -1,5 +1,9 @@
+"""The MX converters' scale operand with the bit patterns 0, 2^-127 and 2^-130 (fp32 denormals) against the oracle's encoder of
+2^127 * x: the hardware reads the operand as E8M0 (exponent field only).  python tests/probe_tiny_scale.py   (under tests/ because it
+asks the oracle; tests/test_hw_gpu.py pins the same fact in the suite)"""
 import sys, os
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo")); sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "tests"))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 from micromix_amd import _lib
 from oracle import mx_oracle as o
