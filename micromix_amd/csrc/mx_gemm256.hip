@@ -141,13 +141,13 @@ namespace mm {
 constexpr int SPLIT_WG_FLOATS = g128::NACC * g128::NT;  // 32768 floats = 128 KiB of partial sums per workgroup
 
 __global__ void __launch_bounds__(256) splitk_reduce_kernel(GemmArgs a, int tiles_n, int total) {
-    // one thread = four consecutive lanes' copies of one accumulator register: 16-byte loads of the partial sums, and the four
-    // results are four consecutive features of one token (8-byte store)
+    // one thread = four consecutive accumulator registers of one lane of the GEMM workgroup (16 bytes of every split's partial sums,
+    // the threads' pieces side by side): four consecutive tokens of one feature
     const int e = (blockIdx.x * 256 + threadIdx.x) * 4;
     if (e >= total) return;
-    // e = (tile, accumulator register r, thread tid of the GEMM workgroup): consecutive threads read consecutive floats
-    const int tid = e & (g128::NT - 1), r = (e >> 9) & (g128::NACC - 1), tile = e >> 15;
-    const float *p = a.ws + ((size_t)tile * a.splits * g128::NACC + r) * g128::NT + tid;
+    // e = (tile, register quad r4, thread tid of the GEMM workgroup, 4 registers): the layout AccLoop::store writes
+    const int tid = (e >> 2) & (g128::NT - 1), r4 = (e >> 11) & (g128::NACC / 4 - 1), tile = e >> 15;
+    const float *p = a.ws + (size_t)tile * a.splits * SPLIT_WG_FLOATS + (e & (SPLIT_WG_FLOATS - 1));
     float run[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
     for (int seg = 0; seg < 3; ++seg) {
@@ -164,31 +164,25 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(GemmArgs a, int tile
         }
     }
     // accumulator layout of the tile kernel: wave = 2 * wm + wn owns tokens wm*32.., features wn*128..; register r of
-    // MFMA tile tn = r >> 4: token (r & 3) + 8 * ((r >> 2) & 3) + 4 * (lane >> 5), feature tn*32 + (lane & 31)
+    // MFMA tile tn = r >> 4: token (r & 3) + 8 * ((r >> 2) & 3) + 4 * (lane >> 5), feature tn*32 + (lane & 31); r = 4 * r4 + i
     const int wave = tid >> 6, lane = tid & 63, wm = wave >> 1, wn = wave & 1;
-    const int m = (tile / tiles_n) * g128::BM + wm * 32 + (r & 3) + 8 * ((r >> 2) & 3) + 4 * (lane >> 5);
-    const int n = (tile % tiles_n) * g128::BN + wn * 128 + (r >> 4) * 32 + (lane & 31);   // lane & 3 == 0
-    if (m >= a.M) return;
+    const int m = (tile / tiles_n) * g128::BM + wm * 32 + 8 * (r4 & 3) + 4 * (lane >> 5);      // + i
+    const int n = (tile % tiles_n) * g128::BN + wn * 128 + (r4 >> 2) * 32 + (lane & 31);
+    if (n >= a.N) return;
     if (a.out_f32) {     // MM_OUT_F32: the fp32 sums themselves
         float *d32 = reinterpret_cast<float *>(a.D) + (size_t)m * a.N + n;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            if (n + i < a.N) d32[i] = run[i];
+            if (m + i < a.M) d32[(size_t)i * a.N] = run[i];
         return;
     }
-    uint32_t b[4];
+    const float bias = a.bias != nullptr ? bf16_bits_to_f32(a.bias[n]) : 0.0f;
+    uint16_t *dst = a.D + (size_t)m * a.N + n;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        b[i] = f32_to_bf16_bits(run[i]);
-        if (a.bias != nullptr && n + i < a.N) b[i] = f32_to_bf16_bits(bf16_bits_to_f32(b[i]) + bf16_bits_to_f32(a.bias[n + i]));
-    }
-    uint16_t *dst = a.D + (size_t)m * a.N + n;
-    if ((a.N & 3) == 0 && n + 3 < a.N) {
-        *reinterpret_cast<uint2 *>(dst) = make_uint2(b[0] | (b[1] << 16), b[2] | (b[3] << 16));
-    } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if (n + i < a.N) dst[i] = (uint16_t)b[i];
+        uint32_t b = f32_to_bf16_bits(run[i]);
+        if (a.bias != nullptr) b = f32_to_bf16_bits(bf16_bits_to_f32(b) + bias);
+        if (m + i < a.M) dst[(size_t)i * a.N] = (uint16_t)b;     // a wave's 32 lanes of one token: 64 bytes side by side
     }
 }
 
