@@ -27,7 +27,9 @@ The line also carries
   * `published_config`: the reference's only published configuration (M = 32, N = K = 4096, MXFP6 x MXFP4) timed here;
   * `quantizers`  : rmsnorm_quantize_x / activate_quantize_x / reorder_quantize_x kernel times against the 8 TB/s HBM peak;
   * `power`       : package power / cap / shader clock sampled with rocm-smi DURING the settle phase (the 4096^3 GEMM runs at the
-                   1400 W cap: its time is set by energy).
+                   1400 W cap: its time is set by energy, see DESIGN.md section 4.2);
+  * `roofline.zero_operands`: context for that -- the SAME launch on operands whose codes are all zero (same instructions, same
+                   traffic, multipliers barely switching): kernel time, power and clock when the cap does not bite.  Never `value`.
 `value` is always the K stream launches' figure (the same launch mode `roofline.kernel_us` is measured in); the hipGraph replay of
 the same K launches is reported beside it as `graph_launch_ms_per_step`.
 With --gpus N > 1 (one process per GPU, RCCL): the north-star tensor-parallel path -- each rank holds a 128-aligned K-shard of
@@ -356,6 +358,23 @@ def main():
             # (`power`), see DESIGN.md section 4.2
             "sustained_mfma_only_tflops": SUSTAINED_MFMA_FP8_FP4, "frac_of_sustained_mfma_only": round(achieved / SUSTAINED_MFMA_FP8_FP4, 4),
         }
+        if not args.no_extras:
+            # context, not the headline: the SAME launch on operands whose codes are all zero -- the same instructions and memory
+            # traffic, but the multipliers barely switch, so the package stays under its power cap and the clock at its maximum.
+            # The gap to `kernel_us` is what the power cap costs on the bench's random data (tools/gemm_data_power.py).
+            az = mixedgemm.reorder_quantize_x(torch.zeros_like(x), idx, *SPLIT)
+            bz = mixedgemm.reorder_quantize_w4(torch.zeros_like(w), idx, *SPLIT)
+            fz = lambda: mm(az, bz, out)
+            pz = {}
+            thz = sample_power(pz, delay_s=0.4)
+            settle(fz, 1.0)
+            thz.join(timeout=25)
+            kz = kernel_us(fz, args.steps)
+            result["roofline"]["zero_operands"] = {
+                "kernel_us": round(kz, 2), "tflops": round(flop / (kz * 1e-6) / 1e12, 1), "frac_of_peak": round(flop / (kz * 1e-6) / 1e12 / PEAK_TFLOPS_FP8, 4),
+                "power": pz, "note": "same launch, all-zero operand codes: not power-capped (context for `power` / `frac`; never `value`)"}
+            del az, bz
+            settle(step, 0.5)      # back to the bench data's clock / power state for what follows
     if rank == 0 and world == 1 and not args.no_extras:
         # ---- mixed splits against their per-precision rooflines (t* = sum_seg 2*M*N*K_seg / peak(seg)) ----
         mixed = {}
