@@ -37,6 +37,22 @@ struct DynamicLdsOnce {
     }
 };
 
+// resident workgroups per CU of `kernel` at (threads, dynamic LDS): the occupancy query costs ~1 us of host time per launch, so the
+// last answer is kept per calling thread and kernel slot (a layer stack alternates between a handful of shapes)
+struct OccupancyCache {
+    struct Entry { const void *kernel; int dev, threads; size_t lds; int per_cu; };
+    static int get(int slot, const void *kernel, int threads, size_t lds) {
+        static thread_local Entry last[8] = {};
+        Entry &e = last[slot & 7];
+        const int dev = current_device();
+        if (e.kernel == kernel && e.dev == dev && e.threads == threads && e.lds == lds && e.per_cu > 0) return e.per_cu;
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+        e = Entry{kernel, dev, threads, lds, per_cu};
+        return per_cu;
+    }
+};
+
 constexpr int MM_MAX_SPLITS = 16;   // in-kernel split-K: splits per tile
 
 struct GemmArgs {

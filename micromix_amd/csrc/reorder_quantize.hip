@@ -184,12 +184,8 @@ hipError_t launch_reorder_quantize(const void *src, int rows, int K, const int16
     if (lds > 48 * 1024)
         if (hipError_t e = big_lds.ensure(reinterpret_cast<const void *>(reorder_quantize_kernel<false, 1024>), 96 * 1024); e != hipSuccess) return e;
     // one resident wave of workgroups (no tail), each striding over the rows
-    int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kern), threads, lds) != hipSuccess ||
-        per_cu < 1)
-        per_cu = 1;
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int per_cu = OccupancyCache::get(w4 ? 0 : 1, reinterpret_cast<const void *>(kern), threads, lds);
+    const int cus = device_cus();
     int blocks = cus * per_cu;
     // (fewer, fatter workgroups that keep their reorder indices for 2 / 4 / 8 rows were measured: 11.1 -> 11.7 / 15.6 / 23.9 us;
     // one row per workgroup with the occupancy limited to 12 / 8 / 4 workgroups per CU, so that rounds of workgroups overlap
@@ -210,12 +206,8 @@ hipError_t launch_reorder_quantize_grouped(const GroupedQuantArgs &ga, int max_r
     static DynamicLdsOnce big_lds;
     if (lds > 48 * 1024)
         if (hipError_t e = big_lds.ensure(reinterpret_cast<const void *>(reorder_quantize_grouped_kernel<false, 1024>), 96 * 1024); e != hipSuccess) return e;
-    int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kern), threads, lds) != hipSuccess ||
-        per_cu < 1)
-        per_cu = 1;
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int per_cu = OccupancyCache::get(w4 ? 2 : 3, reinterpret_cast<const void *>(kern), threads, lds);
+    const int cus = device_cus();
     int bx = cus * per_cu / ga.ngroups;   // one resident wave of workgroups shared by the groups
     bx = bx < 1 ? 1 : bx;
     bx = max_rows < bx ? max_rows : bx;

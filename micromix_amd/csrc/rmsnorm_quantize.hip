@@ -358,10 +358,7 @@ hipError_t launch_rmsnorm_quantize(const void *src, const void *weight, float ep
         const int which = (threads <= 256 ? 0 : threads <= 512 ? 1 : 2) * 2 + (integer_round ? 1 : 0);
         if (hipError_t e = attr[which].ensure(reinterpret_cast<const void *>(kern), 104 * 1024); e != hipSuccess) return e;
     }
-    int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kern), threads, lds) != hipSuccess ||
-        per_cu < 1)
-        per_cu = 1;
+    const int per_cu = OccupancyCache::get(integer_round ? 4 : 5, reinterpret_cast<const void *>(kern), threads, lds);
     const int cus = device_cus();
     int blocks = cus * per_cu;
     blocks = rows < blocks ? rows : blocks;

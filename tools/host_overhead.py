@@ -30,3 +30,12 @@ print("matmul(out=):                    %.2f us" % t(lambda: mixedgemm.matmul(a[
 lib = _lib.load()
 print("raw ctypes mm_version():         %.2f us" % t(lambda: lib.mm_version()))
 print("torch add (reference point):     %.2f us" % t(lambda: x + x))
+# the C entry points alone (preallocated outputs): what the library itself spends per launch on the host
+pp = lambda t_: t_.data_ptr() if t_.numel() else None
+st = torch.cuda.current_stream().cuda_stream
+qo = mixedgemm.reorder_quantize_x(x, idx, *split)
+print("raw mm_reorder_quantize:         %.2f us" % t(lambda: lib.mm_reorder_quantize(x.data_ptr(), M, K, idx.data_ptr(), *split, 0, *[pp(q) for q in qo], st)))
+nw = torch.ones((K,), dtype=torch.bfloat16, device=dev)
+print("raw mm_rmsnorm_quantize:         %.2f us" % t(lambda: lib.mm_rmsnorm_quantize(x.data_ptr(), nw.data_ptr(), 1e-5, M, K, idx.data_ptr(), *split, 0, *[pp(q) for q in qo], st)))
+args = [pp(t_) for t_ in (a[0], b[0], a[1], b[1], a[2], b[2], a[3], b[3], a[4], b[4], a[5], b[5])]
+print("raw mm_matmul:                   %.2f us" % t(lambda: lib.mm_matmul(*args, M, N, *split, 1, 0, None, out.data_ptr(), st)))
