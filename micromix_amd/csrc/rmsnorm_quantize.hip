@@ -253,10 +253,11 @@ rmsnorm_quantize_products_kernel(const uint16_t *__restrict__ src, const uint16_
             const uint32_t w[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const uint32_t c0 = w[k] & 0xFFFFu, c1 = w[k] >> 16;
-                const uint32_t b0 = ((c0 & 4u) ? planeB : 0u) + ((uint32_t)swizzle_chunk(c0 >> 3) << 4) + ((c0 & 3u) << 2);
-                const uint32_t b1 = ((c1 & 4u) ? planeB : 0u) + ((uint32_t)swizzle_chunk(c1 >> 3) << 4) + ((c1 & 3u) << 2);
-                ix[4 * i + k] = b0 | (b1 << 16);    // < 4K <= 32768: 16 bits each
+                // both 16-bit column indices of the register at once (no carries between the halves: every intermediate stays below
+                // 2^16): chunk q = c >> 3, swizzled (q ^ ((q >> 4) & 3)), byte = plane(c & 4) + 16 q' + 4 (c & 3)
+                uint32_t q2 = (w[k] >> 3) & 0x0FFF0FFFu;                 // K <= 8192: q < 1024
+                q2 ^= (q2 >> 4) & 0x00030003u;
+                ix[4 * i + k] = (q2 << 4) + ((w[k] & 0x00030003u) << 2) + ((w[k] >> 2) & 0x00010001u) * planeB;   // < 4K <= 32768 each
             }
             wch[i] = reinterpret_cast<const uint4 *>(weight)[i * T + g];
         }
