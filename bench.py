@@ -454,6 +454,27 @@ def main():
         dec["q_o_M1"] = {"M": 1, "N": N, "K": K, "split": list(fsplit), "us_per_launch": round(t_dec * 1e6, 2),
                          "weight_stream_TBps": round(wbytes / t_dec / 1e12, 3),
                          "note": "back-to-back launches through the C ABI (direct ctypes calls)"}
+        # the largest decode GEMMs of a Llama-3-8B layer: gate / up (N = 14336), M = 1, the shape QLinearLayer sends to the fused kernel
+        ng = 14336
+        wg = (torch.randn((ng, K), device=dev, dtype=torch.float32) * 0.02).to(torch.bfloat16)
+        bg = mixedgemm.reorder_quantize_w4(wg, idx, *fsplit)
+        del wg
+        og = torch.empty((1, ng), dtype=torch.bfloat16, device=dev)
+        wpg = [t.data_ptr() if t.numel() else None for t in bg]
+        fg = lambda: lib.mm_qlinear_decode(xd.data_ptr(), idx.data_ptr(), *wpg, 1, ng, *fsplit, 1, 0, None, og.data_ptr(), stream_ptr)
+        assert fg() == 0
+        settle(fg, 0.2)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(200):
+            fg()
+        torch.cuda.synchronize()
+        t_g = (time.perf_counter() - t0) / 200
+        gbytes = ng * K // 2 + ng * K // 32
+        dec["gate_up_M1"] = {"M": 1, "N": ng, "K": K, "split": list(fsplit), "us_per_launch": round(t_g * 1e6, 2),
+                             "weight_stream_TBps": round(gbytes / t_g / 1e12, 3),
+                             "note": "448 feature blocks walked by one workgroup per CU (the activation row is quantized once per workgroup)"}
+        del bg
         result["decode"] = dec
         del bf
         result["few_tiles"] = few

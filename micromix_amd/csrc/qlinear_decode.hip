@@ -210,46 +210,50 @@ __global__ void __launch_bounds__(NT) qlinear_decode_kernel(Args a) {
     const int pN = L.pN, pS = L.pS, pO = L.pO, Gt = L.Gt, gN = L.gN, gS = L.gS;
 
     // ---- phase 2: weight-streaming GEMM, 32 features per workgroup, K split over the 8 waves (mx_gemm_skinny.hip) ----
-    const int n0 = blockIdx.x * BN;
+    // A workgroup walks the feature blocks blockIdx.x, blockIdx.x + gridDim.x, ...: with more blocks than resident workgroups
+    // (fused gate + up: N = 28672 -> 896 blocks) the quantization of phase 1 -- as long as the streaming of one block's 64 KB of
+    // weights -- is paid once per RESIDENT workgroup instead of once per block.
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nseg[3] = {a.K[0] >> 7, a.K[1] >> 7, a.K[2] >> 7};
-    v16f accN, accS, accO;
+    for (int n0 = blockIdx.x * BN; n0 < a.N; n0 += gridDim.x * BN) {
+        v16f accN, accS, accO;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) accN[i] = accS[i] = accO[i] = 0.0f;
-    if (nseg[0]) run_segment<EL_FP4, EL_FP4>(accN, opN, pN, scales, Gt, a.W[0], a.SFW[0], nseg[0], a.M, a.N, n0, a.sfw_row_tiles);
-    if (nseg[1]) run_segment<EL_FP6, (W4 ? EL_FP4 : EL_FP6)>(accS, opS, pS, scales + gN, Gt, a.W[1], a.SFW[1], nseg[1], a.M, a.N, n0, a.sfw_row_tiles);
-    if (nseg[2]) run_segment<EL_FP8, (W4 ? EL_FP4 : EL_FP8)>(accO, opO, pO, scales + gN + gS, Gt, a.W[2], a.SFW[2], nseg[2], a.M, a.N, n0, a.sfw_row_tiles);
+        for (int i = 0; i < 16; ++i) accN[i] = accS[i] = accO[i] = 0.0f;
+        if (nseg[0]) run_segment<EL_FP4, EL_FP4>(accN, opN, pN, scales, Gt, a.W[0], a.SFW[0], nseg[0], a.M, a.N, n0, a.sfw_row_tiles);
+        if (nseg[1]) run_segment<EL_FP6, (W4 ? EL_FP4 : EL_FP6)>(accS, opS, pS, scales + gN, Gt, a.W[1], a.SFW[1], nseg[1], a.M, a.N, n0, a.sfw_row_tiles);
+        if (nseg[2]) run_segment<EL_FP8, (W4 ? EL_FP4 : EL_FP8)>(accO, opO, pO, scales + gN + gS, Gt, a.W[2], a.SFW[2], nseg[2], a.M, a.N, n0, a.sfw_row_tiles);
 
-    // cross-wave reduction per segment with the reference's rounding chain (as mx_gemm_skinny.hip)
-    float run[2] = {0.0f, 0.0f};
-    auto reduce = [&](const v16f &acc) {
-        __syncthreads();
+        // cross-wave reduction per segment with the reference's rounding chain (as mx_gemm_skinny.hip)
+        float run[2] = {0.0f, 0.0f};
+        auto reduce = [&](const v16f &acc) {
+            __syncthreads();     // (also: the previous block's / segment's sums have been read)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) red[wave][i][lane] = acc[i];
-        __syncthreads();
+            for (int i = 0; i < 16; ++i) red[wave][i][lane] = acc[i];
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int e = threadIdx.x + NT * j;
+                float s = 0.0f;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) s += (&red[w][0][0])[e];
+                s += run[j];
+                run[j] = a.round_per_segment ? bf16_bits_to_f32(f32_to_bf16_bits(s)) : s;
+            }
+        };
+        if (nseg[0]) reduce(accN);
+        if (nseg[1]) reduce(accS);
+        if (nseg[2]) reduce(accO);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int e = threadIdx.x + NT * j;
-            float s = 0.0f;
-#pragma unroll
-            for (int w = 0; w < NW; ++w) s += (&red[w][0][0])[e];
-            s += run[j];
-            run[j] = a.round_per_segment ? bf16_bits_to_f32(f32_to_bf16_bits(s)) : s;
-        }
-    };
-    if (nseg[0]) reduce(accN);
-    if (nseg[1]) reduce(accS);
-    if (nseg[2]) reduce(accO);
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int e = threadIdx.x + NT * j;
-        const int l = e & 63, i = (e >> 6) & 15;
-        const int m = (i & 3) + 8 * (i >> 2) + 4 * (l >> 5);
-        const int n = n0 + (l & 31);
-        if (m < a.M && n < a.N) {
-            uint32_t b = f32_to_bf16_bits(run[j]);
-            if (a.bias != nullptr) b = f32_to_bf16_bits(bf16_bits_to_f32(b) + bf16_bits_to_f32(a.bias[n]));
-            a.D[(size_t)m * a.N + n] = (uint16_t)b;
+            const int l = e & 63, i = (e >> 6) & 15;
+            const int m = (i & 3) + 8 * (i >> 2) + 4 * (l >> 5);
+            const int n = n0 + (l & 31);
+            if (m < a.M && n < a.N) {
+                uint32_t b = f32_to_bf16_bits(run[j]);
+                if (a.bias != nullptr) b = f32_to_bf16_bits(bf16_bits_to_f32(b) + bf16_bits_to_f32(a.bias[n]));
+                a.D[(size_t)m * a.N + n] = (uint16_t)b;
+            }
         }
     }
 }
@@ -445,7 +449,17 @@ hipError_t launch_qlinear_decode(const void *X, const int16_t *idx, const uint8_
     if (hipError_t e = done[(f16 ? 2 : 0) + (w4 ? 0 : 1)].ensure(reinterpret_cast<const void *>(kern), (int)DECODE_LDS_MAX); e != hipSuccess)
         return e;
     const int feat = f16 ? BN16 : BN;
-    hipLaunchKernelGGL(kern, dim3((N + feat - 1) / feat), dim3(NT), lds, stream, a);
+    int blocks = (N + feat - 1) / feat;
+    if (!f16) {
+        // The 32-feature kernel walks its feature blocks (see its phase 2): one workgroup per CU.  Measured (tools/time_decode.py,
+        // K = 4096, (2048,128,1920), one box, us at M = 1 / 4 / 8): gate/up N = 14336 one workgroup per block 13.0 / 16.0 / 20.2,
+        // one per CU 11.4 / 13.4 / 15.8, two per CU 13.1 / 16.1 / 20.2; fused gate + up N = 28672: 26.1 / 32.3 / 40.2 against
+        // 20.9 / 23.1 / 25.4 (two per CU 22.7 / 26.6 / 31.3).  MICROMIX_DECODE_PERSIST=0 restores one workgroup per block (A/B runs).
+        static const bool persist = [] { const char *e = getenv("MICROMIX_DECODE_PERSIST"); return !(e && e[0] == '0'); }();
+        const int resident = device_cus();
+        if (persist && blocks > resident) blocks = resident;
+    }
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(NT), lds, stream, a);
     return hipGetLastError();
 }
 

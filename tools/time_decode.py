@@ -20,7 +20,7 @@ for name, N, K, split in (("q/o", 4096, 4096, (2048, 128, 1920)), ("qkv fused", 
                           ("gate/up", 14336, 4096, (2048, 128, 1920)), ("gate+up fused", 28672, 4096, (2048, 128, 1920)),
                           ("down", 4096, 14336, (7168, 512, 6656))):
     w = (torch.randn((N, K), generator=g) * 0.02).to(torch.bfloat16).to(dev)
-    for M in (1, 4, 8):
+    for M in (1, 2, 4, 8):
         x = torch.randn((M, K), generator=g).to(torch.bfloat16).to(dev)
         idx = torch.argsort(x.float().abs().mean(0)).to(torch.int16)
         b = mixedgemm.reorder_quantize_w4(w, idx, *split)
