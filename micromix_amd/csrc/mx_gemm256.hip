@@ -425,6 +425,10 @@ static TilePlan plan_tiles(int M, int N, const int K[3], bool w4, bool have_ws, 
 // 11-14 us flat, so the tiles win once N / 32 exceeds the CUs (gate/up, N = 14336: 22-25 -> 14 us); and a long K that the model
 // would split (down_proj, K = 14336: 25-30 us skinny) goes to the split-K tiles when the caller brought a workspace.
 bool mx_gemm_small_m_uses_tiles(int M, int N, const int K[3], bool w4, size_t ws_bytes, bool force_split) {
+    // 16 < M <= 32: only with more than three rounds of 32-feature workgroups (fused gate + up, N = 28672: the 64-row tiles take
+    // 19.2-20.0 us at M = 17 / 24 / 32, the weight-streaming kernel 20.7 / 22.1 / 23.9; at N <= 24576 the latter wins or ties:
+    // tools/time_skinny_big_n.py, profiles/notes_r03.md section 24)
+    if (M > 16 && M <= 32) return (N + 31) / 32 > 3 * device_cus();
     if (M <= 32 || M > 64) return M > 64;
     if ((N + 31) / 32 > device_cus()) return true;
     if (ws_bytes == 0) return false;
