@@ -114,4 +114,19 @@ __device__ __forceinline__ void store16(uint8_t *out, uint32_t a, uint32_t b, ui
     *reinterpret_cast<uint4 *>(out) = make_uint4(a, b, c, d);
 }
 
+// The four scale bytes of a row and one 128-column slab: one dword, write-through.  A 128-byte line of a scale tensor collects the
+// entries of 32 rows, every row from another workgroup, so these are the most scattered stores of the quantizers (16 lines per wave
+// instruction, 4 bytes each): 1 % of the bytes but 0.7 us of reorder_quantize's 9.3 at 4096 x 4096 (measured without them).  As
+// plain stores their dirty lines wait in the L2s for the end of the kernel; write-through takes 0.35 us off (8.65 -> 8.3 us on
+// (2048,128,1920)).  Dealing the rows to workgroups so that all writers of a line share an XCD (one L2 merges them) did not help.
+// (reorder_quantize and rmsnorm_quantize; in direct_quantize.hip, whose waves write the scales of 64 consecutive groups, the same
+// write-through COSTS 3 us of 41: it keeps plain stores.)
+__device__ __forceinline__ void store_scale_dword(uint8_t *p, uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("global_store_dword %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+#else
+    *reinterpret_cast<uint32_t *>(p) = v;
+#endif
+}
+
 }  // namespace mm

@@ -123,7 +123,7 @@ __device__ __forceinline__ void reorder_quantize_body(const uint16_t *__restrict
             const uint32_t b2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)byte, 0xAA, 0xF, 0xF, false);
             const uint32_t b3 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)byte, 0xFF, 0xF, 0xF, false);
             if ((g & 3) == 0)
-                *reinterpret_cast<uint32_t *>(sf + sf_offset(r, j, kseg)) = byte | (b1 << 8) | (b2 << 16) | (b3 << 24);
+                store_scale_dword(sf + sf_offset(r, j, kseg), byte | (b1 << 8) | (b2 << 16) | (b3 << 24));
         }
 #if MM_CLOCKS
         if (ck != nullptr && threadIdx.x == 0 && r == first_row) ck[2] = __builtin_amdgcn_s_memrealtime();

@@ -214,7 +214,7 @@ rmsnorm_quantize_kernel(const uint16_t *__restrict__ src, const uint16_t *__rest
             const uint32_t b2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)byte, 0xAA, 0xF, 0xF, false);
             const uint32_t b3 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)byte, 0xFF, 0xF, 0xF, false);
             if ((g & 3) == 0)
-                *reinterpret_cast<uint32_t *>(sf + sf_offset(r, j, kseg)) = byte | (b1 << 8) | (b2 << 16) | (b3 << 24);
+                store_scale_dword(sf + sf_offset(r, j, kseg), byte | (b1 << 8) | (b2 << 16) | (b3 << 24));
         }
         __syncthreads();  // the row and part[] are rewritten by the next iteration
         store_code_image(image, bytesS, KO, oS, oO, r);   // (read here, rewritten only after the next iteration's first barrier)
@@ -332,7 +332,7 @@ rmsnorm_quantize_products_kernel(const uint16_t *__restrict__ src, const uint16_
             const uint32_t b2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)byte, 0xAA, 0xF, 0xF, false);
             const uint32_t b3 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)byte, 0xFF, 0xF, 0xF, false);
             if ((g & 3) == 0)
-                *reinterpret_cast<uint32_t *>(sf + sf_offset(r, j, kseg)) = byte | (b1 << 8) | (b2 << 16) | (b3 << 24);
+                store_scale_dword(sf + sf_offset(r, j, kseg), byte | (b1 << 8) | (b2 << 16) | (b3 << 24));
         }
         __syncthreads();  // the row and part[] are rewritten by the next iteration
         store_code_image(image, bytesS, KO, oS, oO, r);   // (read here, rewritten only after the next iteration's first barrier)
