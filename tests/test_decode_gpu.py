@@ -12,7 +12,8 @@ pytestmark = pytest.mark.gpu
 
 CASES = [(1, 128, 128, (128, 0, 0)), (1, 256, 4096, (0, 0, 4096)), (3, 200, 1024, (512, 128, 384)), (8, 384, 2048, (1024, 512, 512)),
          (2, 160, 5120, (4096, 512, 512)), (8, 128, 14336, (7168, 512, 6656)), (5, 96, 384, (0, 384, 0)), (7, 1024, 512, (256, 0, 256)),
-         (2, 4128, 256, (128, 0, 128)), (8, 4200, 384, (128, 128, 128))]   # N > 4096: the 32-feature kernel (fewer than 16-feature workgroups per CU)
+         (2, 4128, 256, (128, 0, 128)), (8, 4200, 384, (128, 128, 128)),   # N > 4096: the 32-feature kernel (fewer than 16-feature workgroups per CU)
+         (3, 8230, 256, (128, 0, 128)), (1, 16400, 384, (128, 128, 128))]  # more feature blocks than CUs: one workgroup per CU walks them (ragged last block)
 
 
 @pytest.mark.parametrize("wmode", ("w4", "w"))
