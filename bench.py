@@ -138,8 +138,18 @@ def sample_power(out, delay_s=0.6):
     def run():
         try:
             time.sleep(delay_s)
-            txt = subprocess.run(["rocm-smi", "--showpower", "--showmaxpower", "--showclocks", "--json"], capture_output=True,
-                                 text=True, timeout=20).stdout
+            # rocm-smi is a `#!/usr/bin/env python3` script: under rocprofv3 the child would inherit the profiler's preload, and with a
+            # --pmc pass that preload initialises the GPU before the env -> python3 exec, which this pool forbids.  So: the script
+            # itself under this interpreter, with the profiler's variables stripped; and no sampling at all under a counter pass.
+            env = {k: v for k, v in os.environ.items()
+                   if k not in ("LD_PRELOAD", "HSA_TOOLS_LIB") and not k.startswith(("ROCP", "ROCPROF", "ROCTRACER"))}
+            if any(k.startswith("ROCPROF") and "PMC" in k for k in os.environ) or os.environ.get("ROCPROF_COUNTERS"):
+                out["error"] = "skipped under a rocprofv3 counter pass"
+                return
+            script = "/opt/rocm/libexec/rocm_smi/rocm_smi.py"
+            cmd = [sys.executable, script] if os.path.exists(script) else ["rocm-smi"]
+            txt = subprocess.run(cmd + ["--showpower", "--showmaxpower", "--showclocks", "--json"], capture_output=True,
+                                 text=True, timeout=20, env=env).stdout
             card = next(iter(json.loads(txt[txt.index("{"):]).values()))
             for k, v in card.items():
                 kl = k.lower()

@@ -166,6 +166,40 @@ int mm_matmul_ws(const uint8_t *AN, const uint8_t *BN, const uint8_t *AS, const 
                  const uint8_t *BO, const uint8_t *SFAN, const uint8_t *SFBN, const uint8_t *SFAS, const uint8_t *SFBS,
                  const uint8_t *SFAO, const uint8_t *SFBO, int M, int N, int KN, int KS, int KO, int wmode, int flags,
                  const void *bias_bf16, void *D_bf16, void *workspace, size_t workspace_bytes, mm_stream_t stream);
+/*
+ * gate_proj + up_proj + silu(gate) * up + MX quantization for down_proj as ONE launch (M > 64).  Replaces the reference's
+ *     gate = gate_proj(x); up = up_proj(x); h = act_fn(gate) * up; down_proj quantizes h        (model/qLlamaLayer.py:377-387)
+ * and this library's own three-op form  mm_matmul (twice) -> mm_activate_quantize (mgemm/src/activate.cu:44-202,
+ * bindings.cpp:307-334) with the bytes of the latter: gate and up are rounded to bf16 as mm_matmul rounds them, silu * up and the
+ * quantization are those of mm_activate_quantize, so the outputs are bit-identical to that pair -- without the [M, 2 I] bf16
+ * round trip through HBM.
+ *   A*, SFA*         the quantized activations x, as for mm_matmul ([M, K], split KN | KS | KO)
+ *   B*, SFB*         ONE packed fp4 weight of 2 I rows (MM_W_FP4 layout: [2I, KN/2], [2I, KS/2], [2I, KO/2] + scale tensors): rows
+ *                    [256 j, 256 j + 128) are gate_proj's rows [128 j, 128 j + 128), rows [256 j + 128, 256 j + 256) up_proj's rows of
+ *                    the same indices (both packed with x's reorder index; scale tensors interleave the same way, one 128-row tile =
+ *                    (Kseg/128) * 512 bytes).  I must be a multiple of 128.
+ *   DN, DS, DO       the consumer's (down_proj's) split of its K = I input features, natural column order as mm_activate_quantize
+ *   o*, sf*          the consumer's activation operands: [M, DN/2], [M, 3 DS/4], [M, DO] and scale tensors of mm_sf_bytes_x(M, D*) bytes
+ *   flags            MM_ROUND_PER_SEGMENT (default) or MM_ROUND_ONCE: the rounding of gate / up, as mm_matmul
+ *   workspace        only for M <= 64 (mm_gate_up_activate_workspace_bytes(M, I) > 0): M * 2 I bf16 values of scratch, 16-byte aligned;
+ *                    those sizes run the weight-streaming GEMM into it and the activation quantizer on it (same bytes, two launches)
+ */
+size_t mm_gate_up_activate_workspace_bytes(int M, int I);
+int mm_gate_up_activate(const uint8_t *AN, const uint8_t *BN, const uint8_t *AS, const uint8_t *BS, const uint8_t *AO,
+                        const uint8_t *BO, const uint8_t *SFAN, const uint8_t *SFBN, const uint8_t *SFAS, const uint8_t *SFBS,
+                        const uint8_t *SFAO, const uint8_t *SFBO, int M, int I, int KN, int KS, int KO, int DN, int DS, int DO,
+                        int flags, uint8_t *oN, uint8_t *oS, uint8_t *oO, uint8_t *sfN, uint8_t *sfS, uint8_t *sfO, void *workspace,
+                        size_t workspace_bytes, mm_stream_t stream);
+/* which kernels mm_gate_up_activate launches for (M, I) (thread-local buffer, as mm_matmul_describe) */
+const char *mm_gate_up_activate_describe(int M, int I);
+
+/*
+ * Re-arms a workspace for MM_WS_TICKETS_ZEROED: queues a one-workgroup kernel on `stream` that clears its first MM_WS_TICKET_BYTES
+ * (a kernel node when the stream is being captured into a hipGraph; `workspace` must be 16-byte aligned).  Call it when the workspace is created, inside every graph capture that uses a
+ * workspace of its own, and after a launch that did not complete (a fault or a reset mid-launch can leave a ticket counter of the
+ * in-kernel split-K non-zero, and a later launch on that workspace would then never see its last arrival and never write that tile).
+ */
+int mm_matmul_ws_reset(void *workspace, size_t workspace_bytes, mm_stream_t stream);
 
 /*
  * Grouped GEMM (MoE experts; reference caller: the per-expert loop of model/qMixtralLayer.py:507-519, one matmul per expert and

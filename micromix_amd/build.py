@@ -24,7 +24,7 @@ DIAG_LIB = os.path.join(LIBDIR, "libmicromix_diag.so")
 SOURCES = ["capi.hip", "reorder_quantize.hip", "direct_quantize.hip", "rmsnorm_quantize.hip", "mx_gemm.hip", "mx_gemm256.hip",
            "mx_gemm_skinny.hip", "qlinear_decode.hip"]
 DIAG_SOURCES = ["diag.hip"]
-HEADERS = ["mx_common.h", "mx_kernels.h", "mx_acc_regs.h", "mx_gemm_tile.inc", "mx_group_convert.h",
+HEADERS = ["mx_common.h", "mx_kernels.h", "mx_acc_regs.h", "mx_gemm_tile.inc", "mx_group_convert.h", "mx_instrument.h", "mx_direct_convert.h",
            os.path.join("..", "..", "include", "micromix_hip.h"), os.path.join("..", "..", "include", "micromix_diag.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 
@@ -55,39 +55,36 @@ def needs_build() -> bool:
     return False
 
 
-GUARDED = "mx_gemm256.hip"     # its 8-wave tile kernels keep their accumulators in asm-owned AGPRs: tools/check_acc_regs.py
+GUARDED = "mx_gemm256.hip"     # its 8-wave tile kernels keep their accumulators in asm-owned AGPRs: _check_acc_regs.py
 
 
 def verify_acc_regs(objdir: str = OBJDIR) -> int:
     """The assembly hipcc generated for mx_gemm256.hip (kept by -save-temps=obj) must not touch an accumulator AGPR outside
     the inline asm; raises RuntimeError otherwise.  Part of every build of that file, whatever its flags."""
-    sys.path.insert(0, os.path.join(os.path.dirname(PKG), "tools"))
-    try:
-        import check_acc_regs
-    finally:
-        sys.path.pop(0)
+    from . import _check_acc_regs as check_acc_regs
     asm = [f for f in os.listdir(objdir) if f.startswith("mx_gemm256") and f.endswith(".s") and "gfx950" in f]
     if not asm:
         raise RuntimeError("no device assembly of mx_gemm256.hip found (was it compiled with -save-temps=obj?)")
     return check_acc_regs.verify(open(os.path.join(objdir, asm[0])).read())
 
 
+def _flags_stamp() -> str:
+    return os.path.join(OBJDIR, "flags.txt")
+
+
 def _flags_changed(flags) -> bool:
-    """objects in OBJDIR were compiled with other flags (an -D ablation build, --keep-temps): they must not be reused"""
-    stamp = os.path.join(OBJDIR, "flags.txt")
-    want = " ".join(flags)
-    if os.path.exists(stamp) and open(stamp).read() == want:
-        return False
-    os.makedirs(OBJDIR, exist_ok=True)
-    with open(stamp, "w") as f:
-        f.write(want)
-    return True
+    """objects in OBJDIR were compiled with other flags (an -D ablation build, --keep-temps): they must not be reused.  The stamp is
+    written by build() only after a successful link, so an interrupted build with new flags is forced again next time."""
+    stamp = _flags_stamp()
+    return not (os.path.exists(stamp) and open(stamp).read() == " ".join(flags))
 
 
 def build(force: bool = False, keep_temps: bool = False, verbose: bool = True, extra_flags=()) -> str:
     flags = [*FLAGS, *extra_flags] + (["-save-temps=obj"] if keep_temps else [])
     if _flags_changed(flags):
         force = True
+        if os.path.exists(_flags_stamp()):
+            os.remove(_flags_stamp())      # whatever happens below, the old stamp no longer describes the objects
     if not force and not needs_build():
         return LIB
     os.makedirs(OBJDIR, exist_ok=True)
@@ -118,6 +115,8 @@ def build(force: bool = False, keep_temps: bool = False, verbose: bool = True, e
         if verbose:
             print("[micromix_amd.build]", " ".join(cmd), flush=True)
         subprocess.check_call(cmd, cwd=LIBDIR)
+    with open(_flags_stamp(), "w") as f:
+        f.write(" ".join(flags))
     return LIB
 
 

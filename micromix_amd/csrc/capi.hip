@@ -188,6 +188,7 @@ int mm_matmul_ws(const uint8_t *AN, const uint8_t *BN, const uint8_t *AS, const 
     a.bias = (const uint16_t *)bias_bf16;
     a.D = (uint16_t *)D_bf16;
     a.out_f32 = out_f32 ? 1 : 0;
+    a.act = 0;
     a.clock_out = g_clock_buf;
     a.ev_start = g_ev_start;
     a.ev_stop = g_ev_stop;
@@ -201,6 +202,82 @@ int mm_matmul_ws(const uint8_t *AN, const uint8_t *BN, const uint8_t *AS, const 
     a.split_first[0] = a.split_first[1] = a.split_first[2] = a.split_first[3] = 0;
     hipError_t e = mm::launch_mx_gemm(a, wmode == MM_W_FP4, (hipStream_t)stream);
     return e == hipSuccess ? MM_OK : fail_hip(e, "mm_matmul");
+}
+
+// A kernel, not hipMemsetAsync: captured into a hipGraph (ROCm 7.2, MI355X) a memset node in front of the GEMM gave the right result
+// on the first replay only (later replays were wrong as if the clearing were no longer ordered before the kernel); a kernel node
+// replays in order (tools/_probe_capture.py, profiles/notes_r04.md).
+static __global__ void ws_reset_kernel(uint4 *p) { p[threadIdx.x] = make_uint4(0u, 0u, 0u, 0u); }
+
+size_t mm_gate_up_activate_workspace_bytes(int M, int I) {
+    if (M <= 0 || I <= 0 || (I % 128)) return 0;
+    return mm::mx_gemm_act_supported(M, 2 * I) ? 0 : (size_t)M * (size_t)(2 * I) * sizeof(uint16_t);
+}
+
+const char *mm_gate_up_activate_describe(int M, int I) {
+    if (M <= 0 || I <= 0 || (I % 128)) return "none";
+    return mm::describe_mx_gemm_act(M, 2 * I);
+}
+
+int mm_gate_up_activate(const uint8_t *AN, const uint8_t *BN, const uint8_t *AS, const uint8_t *BS, const uint8_t *AO,
+                        const uint8_t *BO, const uint8_t *SFAN, const uint8_t *SFBN, const uint8_t *SFAS, const uint8_t *SFBS,
+                        const uint8_t *SFAO, const uint8_t *SFBO, int M, int I, int KN, int KS, int KO, int DN, int DS, int DO,
+                        int flags, uint8_t *oN, uint8_t *oS, uint8_t *oO, uint8_t *sfN, uint8_t *sfS, uint8_t *sfO, void *workspace,
+                        size_t workspace_bytes, mm_stream_t stream) {
+    if (M < 0 || I < 0 || KN < 0 || KS < 0 || KO < 0) return MM_ERR_BAD_ARG;
+    if ((KN % 128) || (KS % 128) || (KO % 128) || KN + KS + KO == 0) return MM_ERR_BAD_SPLIT;
+    if (!split_ok(DN + DS + DO, DN, DS, DO) || DN + DS + DO != I) return MM_ERR_BAD_SPLIT;
+    if (flags & ~MM_ROUND_ONCE) return MM_ERR_BAD_ARG;
+    if (M == 0) return MM_OK;
+    if ((KN && (!AN || !BN || !SFAN || !SFBN)) || (KS && (!AS || !BS || !SFAS || !SFBS)) || (KO && (!AO || !BO || !SFAO || !SFBO)))
+        return MM_ERR_BAD_ARG;
+    if ((DN && (!oN || !sfN)) || (DS && (!oS || !sfS)) || (DO && (!oO || !sfO))) return MM_ERR_BAD_ARG;
+    const int N = 2 * I;
+    if (!mm::mx_gemm_act_supported(M, N)) {
+        // M <= 64: the weight-streaming GEMM into the caller's scratch (columns alternate 128 gate | 128 up), then the activation
+        // quantizer on that layout: the same bytes as the fused epilogue (tests/test_gate_up_gpu.py)
+        if (!workspace || workspace_bytes < (size_t)M * N * sizeof(uint16_t) || ((uintptr_t)workspace & 15)) return MM_ERR_BAD_ARG;
+        const int st = mm_matmul(AN, BN, AS, BS, AO, BO, SFAN, SFBN, SFAS, SFBS, SFAO, SFBO, M, N, KN, KS, KO, MM_W_FP4, flags, nullptr,
+                                 workspace, stream);
+        if (st != MM_OK) return st;
+        hipError_t e = mm::launch_direct_quantize(workspace, (const uint16_t *)workspace + 128, M, DN, DS, DO, 3, oN, oS, oO, sfN, sfS, sfO,
+                                                  (hipStream_t)stream);
+        return e == hipSuccess ? MM_OK : fail_hip(e, "mm_gate_up_activate");
+    }
+    mm::GemmArgs a;
+    a.X[0] = AN; a.X[1] = AS; a.X[2] = AO;
+    a.W[0] = BN; a.W[1] = BS; a.W[2] = BO;
+    a.SFX[0] = SFAN; a.SFX[1] = SFAS; a.SFX[2] = SFAO;
+    a.SFW[0] = SFBN; a.SFW[1] = SFBS; a.SFW[2] = SFBO;
+    a.K[0] = KN; a.K[1] = KS; a.K[2] = KO;
+    a.M = M; a.N = N;
+    a.sfx_row_tiles = (M + 127) / 128;
+    a.sfw_row_tiles = (N + 127) / 128;
+    a.round_per_segment = (flags & MM_ROUND_ONCE) ? 0 : 1;
+    a.bias = nullptr;
+    a.D = nullptr;
+    a.out_f32 = 0;
+    a.act = 1;
+    a.act_K[0] = DN; a.act_K[1] = DS; a.act_K[2] = DO;
+    a.act_o[0] = oN; a.act_o[1] = oS; a.act_o[2] = oO;
+    a.act_sf[0] = sfN; a.act_sf[1] = sfS; a.act_sf[2] = sfO;
+    a.clock_out = nullptr;
+    a.ev_start = g_ev_start;
+    a.ev_stop = g_ev_stop;
+    a.ws = nullptr; a.ws_bytes = 0; a.splits = 0; a.tickets = nullptr; a.tickets_zeroed = 0;
+    a.n_tile0 = a.n_tiles = 0;
+    a.force_split = 0;
+    a.split_first[0] = a.split_first[1] = a.split_first[2] = a.split_first[3] = 0;
+    hipError_t e = mm::launch_mx_gemm_act(a, (hipStream_t)stream);
+    return e == hipSuccess ? MM_OK : fail_hip(e, "mm_gate_up_activate");
+}
+
+int mm_matmul_ws_reset(void *workspace, size_t workspace_bytes, mm_stream_t stream) {
+    if (!workspace || workspace_bytes < MM_WS_TICKET_BYTES || ((uintptr_t)workspace & 15)) return MM_ERR_BAD_ARG;
+    static_assert(MM_WS_TICKET_BYTES % 16 == 0 && MM_WS_TICKET_BYTES / 16 <= 1024, "one workgroup clears the ticket words");
+    hipLaunchKernelGGL(ws_reset_kernel, dim3(1), dim3(MM_WS_TICKET_BYTES / 16), 0, (hipStream_t)stream, (uint4 *)workspace);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? MM_OK : fail_hip(e, "mm_matmul_ws_reset");
 }
 
 int mm_reorder_quantize_grouped(const mm_quant_group *groups, int ngroups, int K, int KN, int KS, int KO, int mode, mm_stream_t stream) {
@@ -273,6 +350,7 @@ int mm_matmul_grouped(const mm_group *groups, int ngroups, int N, int KN, int KS
         a.bias = (const uint16_t *)g.bias_bf16;
         a.D = (uint16_t *)g.D;
         a.out_f32 = 0;
+        a.act = 0;
         a.clock_out = nullptr;
         a.ev_start = a.ev_stop = nullptr;
         a.ws = nullptr; a.ws_bytes = 0; a.splits = 0; a.force_split = 0; a.n_tile0 = a.n_tiles = 0;

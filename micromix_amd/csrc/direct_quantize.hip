@@ -24,80 +24,10 @@
 // wrong) 41.9 / 46.6 / 41.1; a first rewrite with a lane quad per group (eight elements per lane, 4- and 8-byte stores side by
 // side, fp6 through the old path) 45.4 / 52.8 / 46.8, of which the small stores were 4 ... 12 us.
 #include "mx_common.h"
-// v_cvt_scalef32_2xpk16_bf6_f32 takes two 16-float operands: element order of the packed output, checked on hardware by
-// tests/test_hw_gpu.py::test_f32_converters
-#ifndef MM_BF6_LO
-#define MM_BF6_LO(i) (2 * (i))
-#define MM_BF6_HI(i) (2 * (i) + 1)
-#endif
+#include "mx_direct_convert.h"
 #include "mx_kernels.h"
 
 namespace mm {
-
-typedef short ds2 __attribute__((ext_vector_type(2)));
-typedef float f16v __attribute__((ext_vector_type(16)));
-typedef unsigned du6 __attribute__((ext_vector_type(6)));
-
-// smallest e with FMAX * 2^e >= amax (amax > 0, any fp32), clamped to [-127, 127]
-template <int EL>
-__device__ __forceinline__ int scale_exponent_f32(float amax) {
-    using T = ElemTraits<EL>;
-    const uint32_t a = __float_as_uint(amax);
-    const int exp = (int)(a >> 23);
-    const uint32_t mant = a & 0x7FFFFFu;
-    int e = exp - 127 - T::FMAX_EXP + (mant > T::FMAX_MANT ? 1 : 0);
-    e = exp == 0 ? -127 : e;
-    return e < -127 ? -127 : (e > 127 ? 127 : e);
-}
-
-template <int EL>
-__device__ __forceinline__ uint32_t quantize32(const float (&v)[32], uint8_t *__restrict__ out) {
-    float amax = 0.0f;
-#pragma unroll
-    for (int i = 0; i < 32; ++i) amax = fmaxf(amax, fabsf(v[i]));
-    int e = 0;                                   // scale 1.0
-    if (amax > 1e-6f) e = scale_exponent_f32<EL>(amax);
-    const int ec = e < -126 ? -126 : e;          // 2^-127 is not a normal fp32; only reachable for amax < FMAX * 2^-127
-    const float scale = __uint_as_float((uint32_t)(127 + ec) << 23);
-    if constexpr (EL == EL_FP8) {
-        uint32_t w[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            ds2 r = {0, 0};
-            r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(r, v[4 * i], v[4 * i + 1], scale, false);
-            r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(r, v[4 * i + 2], v[4 * i + 3], scale, true);
-            __builtin_memcpy(&w[i], &r, 4);
-        }
-        uint4 *o = reinterpret_cast<uint4 *>(out);
-        o[0] = make_uint4(w[0], w[1], w[2], w[3]);
-        o[1] = make_uint4(w[4], w[5], w[6], w[7]);
-    } else if constexpr (EL == EL_FP4) {
-        uint32_t w[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            uint32_t r = 0;
-            r = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(r, v[8 * i], v[8 * i + 1], scale, 0);
-            r = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(r, v[8 * i + 2], v[8 * i + 3], scale, 1);
-            r = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(r, v[8 * i + 4], v[8 * i + 5], scale, 2);
-            r = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(r, v[8 * i + 6], v[8 * i + 7], scale, 3);
-            w[i] = r;
-        }
-        store16<true>(out, w[0], w[1], w[2], w[3]);      // write-through: see store16 (mx_group_convert.h)
-    } else {
-        f16v lo, hi;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            lo[i] = v[MM_BF6_LO(i)];
-            hi[i] = v[MM_BF6_HI(i)];
-        }
-        const du6 r = __builtin_amdgcn_cvt_scalef32_2xpk16_bf6_f32(lo, hi, scale);
-        uint2 *o = reinterpret_cast<uint2 *>(out);
-        o[0] = make_uint2(r[0], r[1]);
-        o[1] = make_uint2(r[2], r[3]);
-        o[2] = make_uint2(r[4], r[5]);
-    }
-    return (uint32_t)(e + 127);
-}
 
 // write-through store of 8 bytes (whole lines per wave instruction when the lanes' pieces lie side by side)
 __device__ __forceinline__ void store8_wt(uint8_t *out, uint32_t a, uint32_t b) {
@@ -112,15 +42,6 @@ __device__ __forceinline__ void store8_wt(uint8_t *out, uint32_t a, uint32_t b) 
 // group 16 k + q) fill whole 64-byte runs, the readers (lane m reads chunk i of group m, a 64-byte stride) spread over all banks
 __device__ __forceinline__ int turn_slot(int m, int i) { return 4 * m + (i ^ ((m >> 2) & 3)); }
 
-__device__ __forceinline__ void unpack8(const uint4 t, float *f) {
-    const uint32_t w[4] = {t.x, t.y, t.z, t.w};
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        f[2 * k] = __uint_as_float(w[k] << 16);
-        f[2 * k + 1] = __uint_as_float(w[k] & 0xFFFF0000u);
-    }
-}
-
 // row / group of the wave's group number m (row r0, group g0 = the wave's first)
 __device__ __forceinline__ void locate(int r0, int g0, int m, int G, int &r, int &g) {
     g = g0 + m;
@@ -133,7 +54,10 @@ __device__ __forceinline__ void locate(int r0, int g0, int m, int G, int &r, int
 }
 
 // MODE 0: silu(A) * B -> fp4|fp6|fp8;  MODE 1: A -> fp4|fp6|fp8;  MODE 2: A -> fp4|fp4|fp4
-template <int MODE>
+// INTER (MODE 0 only): A and B are the two halves of ONE row-major [rows, 2 K] matrix whose columns alternate between 128 columns of
+// A and 128 columns of B -- the output of a GEMM over gate / up weight rows interleaved per 128 features (mm_gate_up_activate's
+// small-M path): group g of row r lies at element r * 2 K + (g / 4) * 256 + (g % 4) * 32 of A, and 128 elements further in B.
+template <int MODE, bool INTER = false>
 __global__ void __launch_bounds__(256)
 direct_quantize_kernel(const uint16_t *__restrict__ A, const uint16_t *__restrict__ B, int rows, int KN, int KS, int KO,
                        uint8_t *__restrict__ oN, uint8_t *__restrict__ oS, uint8_t *__restrict__ oO,
@@ -153,9 +77,18 @@ direct_quantize_kernel(const uint16_t *__restrict__ A, const uint16_t *__restric
             uint4 xa[4], xb[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const bool valid = base + 16 * k + (lane >> 2) < total;
-                xa[k] = valid ? pa[64 * k] : make_uint4(0u, 0u, 0u, 0u);
-                if constexpr (MODE == 0) xb[k] = valid ? pb[64 * k] : make_uint4(0u, 0u, 0u, 0u);
+                const long long gi = base + 16 * k + (lane >> 2);
+                const bool valid = gi < total;
+                if constexpr (INTER) {
+                    const long long r = gi / G;
+                    const int g = (int)(gi - r * G);
+                    const size_t at = ((size_t)r * (size_t)(2 * K) + (size_t)(g >> 2) * 256u + (size_t)(g & 3) * 32u) / 8u + (lane & 3);
+                    xa[k] = valid ? reinterpret_cast<const uint4 *>(A)[at] : make_uint4(0u, 0u, 0u, 0u);
+                    xb[k] = valid ? reinterpret_cast<const uint4 *>(B)[at] : make_uint4(0u, 0u, 0u, 0u);
+                } else {
+                    xa[k] = valid ? pa[64 * k] : make_uint4(0u, 0u, 0u, 0u);
+                    if constexpr (MODE == 0) xb[k] = valid ? pb[64 * k] : make_uint4(0u, 0u, 0u, 0u);
+                }
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -181,12 +114,7 @@ direct_quantize_kernel(const uint16_t *__restrict__ A, const uint16_t *__restric
                     unpack8(tb[turn_slot(lane, i)], b);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        // silu(x) * b = x / (1 + e^-x) * b with the hardware exp2 and reciprocal (v_exp_f32, v_rcp_f32: ~1 ulp each; a
-                        // few fp32 ulps in total, like the reference's CUDA expf, whose bits are not reproducible on other hardware
-                        // either).  The full-precision expf + IEEE divide made this kernel ALU bound at 2.4 TB/s.
-                        const float x = v[8 * i + e];
-                        const float ex = __builtin_amdgcn_exp2f(x * -1.4426950408889634f);
-                        v[8 * i + e] = (x * __builtin_amdgcn_rcpf(1.0f + ex)) * b[e];
+                        v[8 * i + e] = silu_mul(v[8 * i + e], b[e]);     // (mx_direct_convert.h)
                     }
                 }
             }
@@ -252,7 +180,9 @@ hipError_t launch_direct_quantize(const void *A, const void *B, int rows, int KN
     const long long total = (long long)rows * ((KN + KS + KO) / 32);
     long long blocks = (total + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
-    auto kern = mode == 0 ? direct_quantize_kernel<0> : (mode == 1 ? direct_quantize_kernel<1> : direct_quantize_kernel<2>);
+    // mode 3 = mode 0 on the interleaved [rows, 2 K] layout (A = the matrix, B = A + 128 elements; the caller passes both)
+    auto kern = mode == 0 ? direct_quantize_kernel<0> : mode == 1 ? direct_quantize_kernel<1> : mode == 2 ? direct_quantize_kernel<2>
+                                                                                                           : direct_quantize_kernel<0, true>;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, stream, (const uint16_t *)A, (const uint16_t *)B, rows, KN, KS, KO,
                        oN, oS, oO, sfN, sfS, sfO);
     return hipGetLastError();

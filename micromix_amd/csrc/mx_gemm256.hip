@@ -36,11 +36,15 @@
 #ifndef MM_FP4_KD256
 #define MM_FP4_KD256 1  // fp4 x fp4 segment on 256-deep slabs (whole cache lines per row); 0 = 128-deep slabs like the other segments
 #endif
+#ifndef MM_XREG
+#define MM_XREG 0   // bit 0: activations of the 256-row tile's fp4 x fp4 segment through registers (mx_gemm_tile.inc, "Hybrid")
+#endif
 #include "mx_instrument.h"   // MM_DBG ablation switches and MM_CLOCKS: constant 0 unless built with -DMM_INSTRUMENT
 #ifndef MM_CHAIN
 #define MM_CHAIN 1  // chained segment hand-over on the 256-row tile (mx_gemm_tile.inc); 0 = every segment's own prologue (A/B builds)
 #endif
 #include "mx_common.h"
+#include "mx_direct_convert.h"
 #include "mx_kernels.h"
 
 namespace mm {
@@ -56,6 +60,13 @@ namespace mm {
 // in-kernel split-K (split_tile_reduce): scope of the ticket atomics and cache-policy bits of the partial-sum traffic
 #define MM_SPLIT_SCOPE __HIP_MEMORY_SCOPE_AGENT
 #define MM_SPLIT_AUX 16   // sc1 = device scope
+#ifndef MM_SPLIT_FENCES
+// 1 = spell the hand-over of the in-kernel split-K with agent-scope release / acquire fences and an acq_rel ticket (split_tile_reduce).
+// Measured (round 4, tools/time_cases.py, k/v at M = 128, back-to-back launches through the Python shim, alternating processes):
+// 23.3 / 23.6 us with the fences against 16.1 / 16.4 us without -- every wave's buffer_wbl2 sc1 walks the L2 although nothing of
+// this kernel is dirty there -- so the default is 0: the same ordering from the instructions that are already needed (see there).
+#define MM_SPLIT_FENCES 0
+#endif
 #define MM_NS g256
 #define MM_MAX_STAGES 3
 #define MM_LDS_BUDGET (160 * 1024)
@@ -532,6 +543,55 @@ hipError_t launch_mx_gemm256(const GemmArgs &a, bool w4, hipStream_t stream) {
             if (w4) return launch_tile(g128::mx_gemm256_kernel<true, false>, done[2], g128::Lds<true>::TOTAL, p.tiles128, g128::NT, a, stream);
             return launch_tile(g128::mx_gemm256_kernel<false, false>, done[3], g128::Lds<false>::TOTAL, p.tiles128, g128::NT, a, stream);
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Tiled GEMM with the fused gate / up epilogue (write_tile_act in mx_gemm_tile.inc; mm_gate_up_activate): 256-feature tiles only
+// (one tile = 128 gate + the 128 up features of the same indices), i.e. the 256 x 256 and 128 x 256 kernels; no split-K.  M <= 64
+// stays with the weight-streaming kernels + the stand-alone activation quantizer (capi.hip).
+// ---------------------------------------------------------------------------------------------------------
+bool mx_gemm_act_supported(int M, int N) { return M > 64 && N > 0 && (N % 256) == 0; }
+
+struct ActPlan { bool use128; int tm256, tm128, tn, tail_cols; };
+static ActPlan plan_act(int M, int N) {
+    ActPlan p{};
+    p.tn = N / 256;
+    p.tm256 = (M + 255) / 256;
+    p.tm128 = (M + 127) / 128;
+    const int cus = device_cus();
+    p.use128 = p.tm128 * p.tn <= cus;          // as plan_tiles: 128-row tiles while they fit one round of workgroups
+    const int tiles256 = p.tm256 * p.tn, rem = tiles256 % cus;
+    // tail balancing as plan_tiles: the last, less-than-half round of 256-row tiles runs as 128-row tiles
+    if (!p.use128 && tiles256 > cus && rem > 0 && 2 * rem <= cus && rem % p.tm256 == 0) p.tail_cols = rem / p.tm256;
+    return p;
+}
+
+const char *describe_mx_gemm_act(int M, int N) {
+    static thread_local char buf[192];
+    if (!mx_gemm_act_supported(M, N)) return "weight-streaming GEMM + mm::direct_quantize_kernel<0,true> (M <= 64)";
+    const ActPlan p = plan_act(M, N);
+    if (p.use128) snprintf(buf, sizeof(buf), "mm::g128::mx_gemm256_act_kernel x %d workgroups (128x256 tiles, fused silu*up + quantize)", p.tm128 * p.tn);
+    else if (p.tail_cols) snprintf(buf, sizeof(buf), "mm::g256::mx_gemm256_act_kernel x %d workgroups (256x256 tiles) + mm::g128::mx_gemm256_act_kernel x %d", p.tm256 * (p.tn - p.tail_cols), p.tm128 * p.tail_cols);
+    else snprintf(buf, sizeof(buf), "mm::g256::mx_gemm256_act_kernel x %d workgroups (256x256 tiles, fused silu*up + quantize)", p.tm256 * p.tn);
+    return buf;
+}
+
+hipError_t launch_mx_gemm_act(const GemmArgs &a, hipStream_t stream) {
+    static DynamicLdsOnce done[2];
+    if (!mx_gemm_act_supported(a.M, a.N)) return hipErrorInvalidValue;
+    const ActPlan p = plan_act(a.M, a.N);
+    if (p.use128) return launch_tile(g128::mx_gemm256_act_kernel, done[1], g128::Lds<true>::TOTAL, p.tm128 * p.tn, g128::NT, a, stream);
+    if (p.tail_cols) {
+        GemmArgs lo = a, hi = a;
+        lo.n_tile0 = 0;
+        lo.n_tiles = p.tn - p.tail_cols;
+        hi.n_tile0 = p.tn - p.tail_cols;
+        hi.n_tiles = p.tail_cols;
+        hipError_t e = launch_tile(g256::mx_gemm256_act_kernel, done[0], g256::Lds<true>::TOTAL, p.tm256 * lo.n_tiles, g256::NT, lo, stream);
+        if (e != hipSuccess) return e;
+        return launch_tile(g128::mx_gemm256_act_kernel, done[1], g128::Lds<true>::TOTAL, p.tm128 * hi.n_tiles, g128::NT, hi, stream);
+    }
+    return launch_tile(g256::mx_gemm256_act_kernel, done[0], g256::Lds<true>::TOTAL, p.tm256 * p.tn, g256::NT, a, stream);
 }
 
 // grouped launch of the tiled kernels: the tile size is chosen for the sum of the groups' tiles with the same round rule as a

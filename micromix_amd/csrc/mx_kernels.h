@@ -79,6 +79,14 @@ struct GemmArgs {
     unsigned long long slot_seg;    // ... two bits per slot: the segment (0 N, 1 S, 2 O) whose partial sum the slot holds
     unsigned *tickets;              // in-kernel split-K (4-wave tiles): one counter per tile at the head of the workspace, zero between launches
     int tickets_zeroed;             // MM_WS_TICKETS_ZEROED: the caller vouches for that
+    // Fused gate / up epilogue (mm_gate_up_activate; launch_mx_gemm_act): W holds 2 * I rows, 128 gate features alternating with
+    // the 128 up features of the same index, and a 256-feature tile quantizes silu(gate) * up of its 128 intermediate features as
+    // activate_quantize_x does -- into act_o / act_sf, the operand tensors of the consumer GEMM whose K split is act_K -- instead of
+    // writing D.
+    int act;
+    int act_K[3];
+    uint8_t *act_o[3];
+    uint8_t *act_sf[3];
     hipEvent_t ev_start, ev_stop;   // diagnostics only (mm_diag_set_kernel_events): recorded at the GEMM dispatch itself
     unsigned long long *clock_out;  // diagnostics only (mm_diag_set_clock_buffer): per workgroup {shader cycles, 100 MHz ticks}
 };
@@ -113,6 +121,7 @@ hipError_t set_quant_clock_buffer(unsigned long long *buf);   // -DMM_INSTRUMENT
 hipError_t launch_reorder_quantize(const void *src, int rows, int K, const int16_t *idx, int KN, int KS, int KO, bool w4,
                                    uint8_t *oN, uint8_t *oS, uint8_t *oO, uint8_t *sfN, uint8_t *sfS, uint8_t *sfO,
                                    hipStream_t stream);
+// mode: 0 silu(A) * B, 1 A (mixed), 2 A (all fp4), 3 = 0 with A | B interleaved per 128 columns in one [rows, 2 K] matrix
 hipError_t launch_direct_quantize(const void *A, const void *B, int rows, int KN, int KS, int KO, int mode, uint8_t *oN,
                                   uint8_t *oS, uint8_t *oO, uint8_t *sfN, uint8_t *sfS, uint8_t *sfO, hipStream_t stream);
 hipError_t launch_rmsnorm_quantize(const void *src, const void *weight, float eps, int rows, int K, const int16_t *idx, int KN,
@@ -124,6 +133,9 @@ hipError_t launch_qlinear_decode(const void *X, const int16_t *idx, const uint8_
                                  hipStream_t stream);
 hipError_t launch_mx_gemm(const GemmArgs &a, bool w4, hipStream_t stream);
 hipError_t launch_mx_gemm256(const GemmArgs &a, bool w4, hipStream_t stream);
+bool mx_gemm_act_supported(int M, int N);                                 // the tiled kernels with the fused gate / up epilogue take this shape
+hipError_t launch_mx_gemm_act(const GemmArgs &a, hipStream_t stream);    // fp4 weights only
+const char *describe_mx_gemm_act(int M, int N);
 hipError_t launch_mx_gemm_skinny(const GemmArgs &a, bool w4, hipStream_t stream);
 hipError_t launch_mx_gemm_skinny_grouped(const GroupedGemmArgs &ga, int max_m, bool w4, hipStream_t stream);
 size_t mx_gemm_workspace_bytes(int M, int N, const int K[3], bool w4, bool force, bool tickets_zeroed);

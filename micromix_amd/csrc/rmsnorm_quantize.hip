@@ -76,7 +76,11 @@ __device__ __forceinline__ float rms_scale(uint32_t (&v)[16], uint32_t amax, int
         // tie, four times the nudge).  |t| >= 128 is an integer already and the nudge stays below 0.5.  The reference's clamp to
         // +-FMAX cannot bite: e is the smallest exponent with FMAX * 2^e >= amax, so |t| <= FMAX, an integer.
         // (Was trunc(t + copysign(0.5, t)): 9 VALU operations per pair, now 6.)
-        const float rs = __uint_as_float(((uint32_t)(127 - e) << 23) | 0x2000u);  // 2^-e * (1 + 2^-10)
+        // (e <= 126 for every finite bf16 absmax: FMAX * 2^126 >= 1.5 * 2^128 is beyond the format; only an inf / NaN block reaches
+        // e = 127, whose exponent field would be 0 here -- a denormal multiplier -- so the multiplier's exponent is capped: such a
+        // block stays inf / NaN through the conversion either way)
+        const int em = e > 126 ? 126 : e;
+        const float rs = __uint_as_float(((uint32_t)(127 - em) << 23) | 0x2000u);  // 2^-e * (1 + 2^-10)
         const f2 rs2 = {rs, rs};
 #pragma unroll
         for (int i = 0; i < 16; ++i) {

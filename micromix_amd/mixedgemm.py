@@ -27,7 +27,7 @@ import torch
 
 from . import _lib
 
-__all__ = ["test_function", "matmul", "reorder_quantize_x", "reorder_quantize_w", "reorder_quantize_w4", "activate_quantize_x",
+__all__ = ["test_function", "matmul", "gate_up_activate", "interleave_gate_up", "reorder_quantize_x", "reorder_quantize_w", "reorder_quantize_w4", "activate_quantize_x",
            "downproj_quantize_w", "downproj_quantize_w4", "rmsnorm_quantize_x", "qlinear_decode", "qlinear_decode_supported", "matmul_grouped", "reorder_quantize_x_grouped"]
 
 
@@ -143,24 +143,44 @@ def reorder_quantize_w4(W, reorder_index, KN, KS, KO):
     return _quantize(W, reorder_index, KN, KS, KO, "w4", "reorder_quantize_w4")
 
 
-_SPLIT_WS = {}
-_SPLIT_WS_RETIRED = []     # outgrown workspaces stay alive: a captured hipGraph may still hold their address
+_SPLIT_WS = {}             # (device index, stream handle) -> workspace tensor; insertion order = age
+_SPLIT_WS_MAX = 8          # eager workspaces kept alive at once (8-128 MiB each): the oldest stream's is released beyond that
 
 
 def split_workspace(dev, nbytes):
-    """The split-K scratch of `dev`'s current stream: one tensor per (device, stream), grown when a shape needs more, its first
-    MM_WS_TICKET_BYTES zero (the C ABI's MM_WS_TICKETS_ZEROED contract: cleared once here, left zero by every launch).  Reuse by
-    consecutive launches of one stream is ordered by the stream; the C ABI itself never allocates.  A workspace that a later,
-    larger shape outgrows is replaced but never freed (sizes at least double, so the total stays below twice the largest)."""
-    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    """The split-K scratch for a launch on `dev`'s current stream, its first MM_WS_TICKET_BYTES zero when that launch runs (the C
+    ABI's MM_WS_TICKETS_ZEROED contract); the C ABI itself never allocates.
+
+    Eager: one tensor per (device, stream), cleared when it is created and left zero by every launch, grown when a shape needs
+    more; consecutive launches of the stream reuse it in stream order.  At most _SPLIT_WS_MAX are kept: dropping a tensor only
+    returns its block to the caching allocator's pool of the stream it was allocated on, which hands it to LATER work of that
+    stream, so queued launches are not disturbed.
+
+    Under hipGraph capture: a tensor of the capture's own (private pool) with a clearing kernel node for its ticket words in front of the
+    launch, on every call.  A captured launch therefore never shares ticket counters with eager work or with another graph --
+    whichever stream the graphs are replayed on, in whatever order -- and nothing depends on a clearing that capture recorded
+    instead of executing (the first capture used to create, and "zero", the capture stream's workspace)."""
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    if torch.cuda.is_current_stream_capturing():
+        t = torch.empty((max(int(nbytes), _lib.MM_WS_TICKET_BYTES),), dtype=torch.uint8, device=dev)
+        with _on_device(dev.index):
+            st = _lib.load().mm_matmul_ws_reset(t.data_ptr(), t.numel(), stream)
+        if st:
+            _lib.check(st, "matmul(workspace)")
+        return t
+    key = (dev.index, stream)
     t = _SPLIT_WS.get(key)
     if t is None or t.numel() < nbytes:
-        if t is not None:
-            _SPLIT_WS_RETIRED.append(t)
         size = max(int(nbytes), 8 << 20, 2 * t.numel() if t is not None else 0)
+        _SPLIT_WS.pop(key, None)
         t = torch.empty((size,), dtype=torch.uint8, device=dev)
-        t[:_lib.MM_WS_TICKET_BYTES].zero_()
+        with _on_device(dev.index):
+            st = _lib.load().mm_matmul_ws_reset(t.data_ptr(), t.numel(), stream)
+        if st:
+            _lib.check(st, "matmul(workspace)")
         _SPLIT_WS[key] = t
+        while len(_SPLIT_WS) > _SPLIT_WS_MAX:
+            _SPLIT_WS.pop(next(iter(_SPLIT_WS)))
     return t
 
 
@@ -256,6 +276,98 @@ def matmul(AN, BN, AS, BS, AO, BO, SFAN, SFBN, SFAS, SFBS, SFAO, SFBO, *, bias=N
     if st:
         _lib.check(st, "matmul")
     return out
+
+
+def interleave_gate_up(gate, up):
+    """(BN, BS, BO, SFBN, SFBS, SFBO) of gate_proj and of up_proj -- same shapes, packed with the SAME reorder index and split, fp4
+    weights -- as the ONE packed weight of 2 I rows that `gate_up_activate` takes: 128 gate rows alternate with the 128 up rows of the
+    same feature indices (one 256-feature GEMM tile then holds everything 128 columns of silu(gate) * up need); the scale tensors,
+    whose 128-row tiles are contiguous blocks of (Kseg / 128) * 512 bytes, interleave the same way.  I must be a multiple of 128."""
+    n = gate[0].size(0)
+    if n % 128 or any(g.shape != u.shape for g, u in zip(gate, up)):
+        raise RuntimeError("gate and up must have identical packed shapes and a multiple of 128 output features")
+    out = []
+    for g, u in zip(gate[:3], up[:3]):
+        w = g.size(1)
+        out.append(torch.stack((g.reshape(n // 128, 128, w), u.reshape(n // 128, 128, w)), dim=1).reshape(2 * n, w).contiguous())
+    for g, u in zip(gate[3:], up[3:]):
+        if g.numel() == 0:
+            out.append(g.clone())
+            continue
+        per = g.numel() // (n // 128)
+        out.append(torch.stack((g.reshape(n // 128, per), u.reshape(n // 128, per)), dim=1).reshape(-1).contiguous())
+    return tuple(out)
+
+
+def deinterleave_gate_up(packed):
+    """inverse of interleave_gate_up: (gate 6-tuple, up 6-tuple), as contiguous copies"""
+    n2 = packed[0].size(0)
+    n = n2 // 2
+    gate, up = [], []
+    for t in packed[:3]:
+        v = t.reshape(n // 128, 2, 128, t.size(1))
+        gate.append(v[:, 0].reshape(n, t.size(1)).contiguous())
+        up.append(v[:, 1].reshape(n, t.size(1)).contiguous())
+    for t in packed[3:]:
+        if t.numel() == 0:
+            gate.append(t.clone())
+            up.append(t.clone())
+            continue
+        v = t.reshape(n // 128, 2, -1)
+        gate.append(v[:, 0].reshape(-1).contiguous())
+        up.append(v[:, 1].reshape(-1).contiguous())
+    return tuple(gate), tuple(up)
+
+
+def gate_up_activate(A, B, DN, DS, DO, *, rounding="reference"):
+    """silu(gate_proj(x)) * up_proj(x), quantized for down_proj, as ONE launch for M > 64 (the reference: model/qLlamaLayer.py:377-387
+    through HBM; its activate_quantize_x, bindings.cpp:307-334).  A = (AN, AS, AO, SFAN, SFAS, SFAO) = reorder_quantize_x(x, ...);
+    B = interleave_gate_up(gate packed, up packed); (DN, DS, DO) = down_proj's split of the I intermediate features in natural
+    column order.  Returns (XN, XS, XO, SFXN, SFXS, SFXO), bit-identical to
+    `activate_quantize_x(matmul(A, gate), matmul(A, up), DN, DS, DO)`.  Not an export of the reference module."""
+    lib = _lib.load()
+    dev = A[0].device
+    index = dev.index
+    u8 = torch.uint8
+    for t in (*A, *B):
+        if not _ok(t, u8, index):
+            _check_tensor(t, "operand", u8, dev)
+    M, N2 = A[0].size(0), B[0].size(0)
+    KN, KS, KO = A[0].size(1) * 2, A[1].size(1) * 4 // 3, A[2].size(1)
+    DN, DS, DO = int(DN), int(DS), int(DO)
+    I = N2 // 2
+    if N2 % 256 or B[0].size(1) != KN // 2 or B[1].size(1) != KS // 2 or B[2].size(1) != KO // 2 or B[1].size(0) != N2 or B[2].size(0) != N2:
+        raise RuntimeError("B must be an interleaved fp4 gate/up weight (interleave_gate_up) matching the activations' split")
+    if A[1].size(0) != M or A[2].size(0) != M:
+        raise RuntimeError("AS and AO must be [M, bytes]")
+    if DN < 0 or DS < 0 or DO < 0 or DN % 128 or DS % 128 or DO % 128 or DN + DS + DO != I:
+        _lib.check(_lib.MM_ERR_BAD_SPLIT, "activate_quantize_x")
+    for n, t, need in (("SFAN", A[3], _sf_bytes_w(M, KN)), ("SFAS", A[4], _sf_bytes_w(M, KS)), ("SFAO", A[5], _sf_bytes_w(M, KO)),
+                       ("SFBN", B[3], _sf_bytes_w(N2, KN)), ("SFBS", B[4], _sf_bytes_w(N2, KS)), ("SFBO", B[5], _sf_bytes_w(N2, KO))):
+        if t.numel() < need:
+            raise RuntimeError(f"{n} holds {t.numel()} scale bytes, needs at least {need}")
+    for t in (*A, *B):
+        if t.data_ptr() & 15 and t.numel():
+            raise RuntimeError("operands must be 16-byte aligned")
+    if rounding not in ("reference", "fused"):
+        raise ValueError("rounding must be 'reference' or 'fused'")
+    flags = _lib.MM_ROUND_PER_SEGMENT if rounding == "reference" else _lib.MM_ROUND_ONCE
+    oN = torch.empty((M, DN // 2), dtype=u8, device=dev)
+    oS = torch.empty((M, DS // 4 * 3), dtype=u8, device=dev)
+    oO = torch.empty((M, DO), dtype=u8, device=dev)
+    sfN = torch.empty((_sf_bytes_x(M, DN),), dtype=u8, device=dev)
+    sfS = torch.empty((_sf_bytes_x(M, DS),), dtype=u8, device=dev)
+    sfO = torch.empty((_sf_bytes_x(M, DO),), dtype=u8, device=dev)
+    ws_bytes = lib.mm_gate_up_activate_workspace_bytes(M, I)
+    ws = torch.empty((ws_bytes,), dtype=u8, device=dev) if ws_bytes else None      # stream-ordered scratch from the caching allocator
+    with _on_device(index):
+        st = lib.mm_gate_up_activate(_ptr(A[0]), _ptr(B[0]), _ptr(A[1]), _ptr(B[1]), _ptr(A[2]), _ptr(B[2]), _ptr(A[3]), _ptr(B[3]),
+                                     _ptr(A[4]), _ptr(B[4]), _ptr(A[5]), _ptr(B[5]), M, I, KN, KS, KO, DN, DS, DO, flags,
+                                     _ptr(oN), _ptr(oS), _ptr(oO), _ptr(sfN), _ptr(sfS), _ptr(sfO),
+                                     _ptr(ws) if ws is not None else None, ws_bytes, _stream_ptr(dev))
+    if st:
+        _lib.check(st, "gate_up_activate")
+    return oN, oS, oO, sfN, sfS, sfO
 
 
 def reorder_quantize_x_grouped(Xs, reorder_indices, KN, KS, KO):

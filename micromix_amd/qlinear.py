@@ -236,3 +236,46 @@ class FusedQLinear(nn.Module):
         if bsz is None:
             return tuple(t.reshape(q_len, -1) for t in y.split(self.splits, dim=1))
         return tuple(t.reshape(bsz, q_len, -1) for t in y.split(self.splits, dim=1))
+
+
+class FusedMLP(nn.Module):
+    """gate_proj, up_proj, act_fn(gate) * up and down_proj of one decoder MLP (model/qLlamaLayer.py:336-387) in three launches
+    instead of the reference's five (quantize x once instead of twice; gate + up + silu * up + the quantization for down_proj as ONE
+    GEMM launch, `mixedgemm.gate_up_activate`; down_proj).  `gate` and `up` are QLinearLayers over the same input with the same
+    reorder index and split (fp4 weights), whose output features are already in down_proj's reordered order -- the reference folds
+    that order into gate / up (`out_reorder_index`, qLlamaLayer.py:341,354); `w_down` [H, I] has its columns in that order and
+    `down_split` = (p4, p6, p8) of the I intermediate features (packed with downproj_quantize_w4, bindings.cpp:363-387).
+    Bit-identical to gate(x), up(x) -> activate_quantize_x -> matmul with the packed down weight."""
+
+    def __init__(self, gate: QLinearLayer, up: QLinearLayer, w_down: torch.Tensor, down_split, rounding: str = "reference"):
+        super().__init__()
+        if (gate.p4_num, gate.p6_num, gate.p8_num) != (up.p4_num, up.p6_num, up.p8_num) or not torch.equal(gate.reorder_index, up.reorder_index) \
+                or gate.out_features != up.out_features or gate.bias is not None or up.bias is not None:
+            raise ValueError("gate and up must share input features, reorder index, split and have no bias")
+        if gate.BS.size(1) != gate.p6_num // 2 or gate.BO.size(1) != gate.p8_num // 2:
+            raise ValueError("the fused MLP needs fp4 weights (weight_mode='w4')")
+        self.hidden, self.inter = gate.in_features, gate.out_features
+        self.in_split = (gate.p4_num, gate.p6_num, gate.p8_num)
+        self.down_split = tuple(int(v) for v in down_split)
+        if sum(self.down_split) != self.inter or tuple(w_down.shape) != (self.hidden, self.inter):
+            raise ValueError("down_split must sum to the intermediate size and w_down must be [hidden, intermediate]")
+        self.rounding = rounding
+        self.reorder_index = gate.reorder_index
+        packed = mixedgemm.interleave_gate_up((gate.BN, gate.BS, gate.BO, gate.SFBN, gate.SFBS, gate.SFBO),
+                                              (up.BN, up.BS, up.BO, up.SFBN, up.SFBS, up.SFBO))
+        for name, t in zip(("BN", "BS", "BO", "SFBN", "SFBS", "SFBO"), packed):
+            self.register_buffer("GU_" + name, t)
+        down = mixedgemm.downproj_quantize_w4(w_down.to(gate.BN.device).to(torch.bfloat16).contiguous(), *self.down_split)
+        for name, t in zip(("BN", "BS", "BO", "SFBN", "SFBS", "SFBO"), down):
+            self.register_buffer("D_" + name, t)
+
+    @torch.no_grad()
+    def forward(self, x):
+        lead = x.shape[:-1]
+        x2 = x.reshape(-1, self.hidden).contiguous()
+        qx = mixedgemm.reorder_quantize_x(x2, self.reorder_index, *self.in_split)
+        qh = mixedgemm.gate_up_activate(qx, (self.GU_BN, self.GU_BS, self.GU_BO, self.GU_SFBN, self.GU_SFBS, self.GU_SFBO),
+                                        *self.down_split, rounding=self.rounding)
+        y = mixedgemm.matmul(qh[0], self.D_BN, qh[1], self.D_BS, qh[2], self.D_BO, qh[3], self.D_SFBN, qh[4], self.D_SFBS, qh[5],
+                             self.D_SFBO, rounding=self.rounding)
+        return y.reshape(*lead, self.hidden)

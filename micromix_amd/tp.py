@@ -113,6 +113,18 @@ class _HipOps:
         from . import mixedgemm
         return mixedgemm.downproj_quantize_w4(w, kn, ks, ko)
 
+    # optional ops (a backend without them makes TPMLP run gate, up and activate_quantize as three steps)
+    @staticmethod
+    def interleave_gate_up(gate, up):
+        from . import mixedgemm
+        return mixedgemm.interleave_gate_up(gate, up)
+
+    @staticmethod
+    def gate_up_activate(a, b, kn, ks, ko):
+        """gate, up, silu(gate) * up and the quantization for down_proj as one launch (mm_gate_up_activate)"""
+        from . import mixedgemm
+        return mixedgemm.gate_up_activate(a, b, kn, ks, ko, rounding="reference")
+
 
 class TPShardedLinear:
     """One QLinear, K-sharded over `world` ranks.  w [N, K] bf16 and reorder_index [K] int16 are the FULL
@@ -288,6 +300,8 @@ class TPMLP:
         g, u = gate_g(qx), up_g(qx)           column-parallel: [M, I_g], complete products, no communication
         qh = activate_quantize_x(g, u, ...)   silu(g) * u -> mixed quantize of the LOCAL slice; every 32-block and its scale are
                                               the ones the unsharded layer computes, because shards are 128-aligned
+                                              (with the HIP backend these two lines are ONE launch, mm_gate_up_activate: g and u
+                                              never leave the CU; bit-identical)
         part = down_g(qh)                     row-parallel partial [M, H], one bf16 rounding
         y = all_reduce(part)                  the only collective: M * H * 2 bytes
     """
@@ -309,9 +323,28 @@ class TPMLP:
         self.empty = self.positions.numel() == 0
         if not self.empty:
             sel = self.positions.to(w_gate.device)
-            self.packed_gate = self.ops.quantize_w4(w_gate[sel].contiguous(), self.in_index, *self.in_split)
-            self.packed_up = self.ops.quantize_w4(w_up[sel].contiguous(), self.in_index, *self.in_split)
+            packed_gate = self.ops.quantize_w4(w_gate[sel].contiguous(), self.in_index, *self.in_split)
+            packed_up = self.ops.quantize_w4(w_up[sel].contiguous(), self.in_index, *self.in_split)
+            # with a backend that has the fused kernel the rank keeps ONE weight, gate and up rows interleaved per 128 features
+            # (mixedgemm.interleave_gate_up); `packed_gate` / `packed_up` are then recovered on demand (tests)
+            self.fused = hasattr(self.ops, "gate_up_activate")
+            if self.fused:
+                self.packed_gate_up = self.ops.interleave_gate_up(packed_gate, packed_up)
+            else:
+                self._packed_gate, self._packed_up = packed_gate, packed_up
             self.packed_down = self.ops.downproj_quantize_w4(w_down[:, sel].contiguous(), *self.widths)
+
+    def _split_gate_up(self):
+        from . import mixedgemm
+        return mixedgemm.deinterleave_gate_up(self.packed_gate_up)
+
+    @property
+    def packed_gate(self):
+        return self._split_gate_up()[0] if self.fused else self._packed_gate
+
+    @property
+    def packed_up(self):
+        return self._split_gate_up()[1] if self.fused else self._packed_up
 
     def quantize_x(self, x2d: torch.Tensor):
         return self.ops.quantize_x(x2d, self.in_index, *self.in_split)
@@ -320,9 +353,12 @@ class TPMLP:
         """this rank's [M, H] partial of the MLP output (None for an empty shard); fp32 = the unrounded accumulator (MM_OUT_F32)"""
         if self.empty:
             return None
-        g = self.ops.matmul(qx, self.packed_gate, rounding="reference")
-        u = self.ops.matmul(qx, self.packed_up, rounding="reference")
-        qh = self.ops.activate_quantize(g, u, *self.widths)
+        if self.fused:
+            qh = self.ops.gate_up_activate(qx, self.packed_gate_up, *self.widths)
+        else:
+            g = self.ops.matmul(qx, self.packed_gate, rounding="reference")
+            u = self.ops.matmul(qx, self.packed_up, rounding="reference")
+            qh = self.ops.activate_quantize(g, u, *self.widths)
         return self.ops.matmul_f32(qh, self.packed_down) if fp32 else self.ops.matmul(qh, self.packed_down)
 
     def forward(self, x: torch.Tensor, fp32_partials: bool = False) -> torch.Tensor:

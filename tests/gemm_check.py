@@ -23,7 +23,8 @@ EPS_HW = 2.0 ** -11
 # Statistics asserted with `strict=True`.  SURVEY.md section 8c proposed "<= 1 bf16 ulp on >= 99.9 % of the elements, <= 2 ulp
 # max" for a comparison with the reference CUDA kernel; against a CPU oracle that sums every block in fp64, and measured over the
 # full Llama / Qwen / Mixtral shapes (tests/test_model_shapes_gpu.py), the honest numbers are:
-#   * FRAC_GT1[mode]: at most 0.3 % (fp4 weights) / 0.4 % (matching-precision weights) of the outputs differ from the oracle by more than one bf16 ulp.  Measured: < 0.05 % on the tiled
+#   * FRAC_GT1: at most 0.3 % of the outputs differ from the oracle by more than one bf16 ulp, in both weight modes (the one case that
+#     measures 0.30 % -- the all-fp8 x fp8 4096^3 product -- passes its own, documented bound: `frac_gt1=` of check_gemm).  Measured: < 0.05 % on the tiled
 #     kernels with mixed splits, 0.10-0.21 % on the weight-streaming kernels (M <= 64: K is split over the 8 waves, so the fp32
 #     sums are associated differently) and on all-MXFP8 activations; "w" mode up to 0.21 %.  Almost all of them are outputs
 #     much smaller than their own terms (cancellation), where one ulp of the sum is many ulps of the result;
@@ -32,21 +33,22 @@ EPS_HW = 2.0 ** -11
 #     measured); an all-MXFP8 activation (split (0, 0, K), K = 4096) measures 98.0-98.8 % bit-equal, mixed splits > 99 %.  With
 #     matching-precision weights ("w") the fp6 x fp6 and fp8 x fp8 block sums carry up to 5e-4 * S, which moves a result across a
 #     rounding boundary more often: 98.2 % measured on the Llama mixed split, 97.3 % (and 0.30 % of the outputs more than one
-#     ulp away) on the all-fp8 x fp8 4096^3 product of tests/test_matmul_gpu.py::test_full_size_properties -- hence 96.5 % and
-#     0.4 % for that mode;
+#     ulp away) on the all-fp8 x fp8 4096^3 product of tests/test_matmul_gpu.py::test_full_size_properties -- hence 96.5 % for
+#     that mode (and FRAC_GT1_W_ALL_FP8 for that one case);
 #   * MAX_ULP over the outputs that are not cancellation results: |want| >= CANCEL * S (S = sum |a||b|) AND |want| >= half of
 #     the largest running value of the rounding chain (after each segment, before / after the bias).  Every rounding stage can
 #     differ from the oracle's by one ulp OF THAT STAGE's magnitude, i.e. up to two ulps of a final value half its size, and
 #     two stages can flip at once: measured 1-2, bound 4.  An output far smaller than its intermediate values has few
 #     significant bits left in ANY summation order (ulp distances of 10^2..10^4 occur there by construction); those outputs are
 #     held to the absolute bound above instead.
-FRAC_GT1 = {"w4": 3e-3, "w": 4e-3}
+FRAC_GT1 = {"w4": 3e-3, "w": 3e-3}
+FRAC_GT1_W_ALL_FP8 = 4e-3      # all-fp8 x fp8, K = 4096 (every block sum carries the adder-tree error): 0.30 % measured
 FRAC_EXACT = {"w4": 0.975, "w": 0.965}
 MAX_ULP = 4
 CANCEL = 2.0 ** -9
 
 
-def check_gemm(got_bits, qx, qw, rounding="reference", eps=EPS_HW, label="", strict=False, wdeq=None, bias_bits=None):
+def check_gemm(got_bits, qx, qw, rounding="reference", eps=EPS_HW, label="", strict=False, wdeq=None, bias_bits=None, frac_gt1=None):
     """asserts the tolerance above (and the statistics, with strict=True); returns a dict of statistics.
     wdeq: cached o.dequant_operand(qw, "w", wmode); bias_bits: [N] bf16 bits added the reference's way (qLinearLayer.py:70-71:
     y = bf16(y + bias)) to the oracle result before the comparison."""
@@ -86,7 +88,7 @@ def check_gemm(got_bits, qx, qw, rounding="reference", eps=EPS_HW, label="", str
     assert not bad.any(), f"{label}: {int(bad.sum())} elements outside tolerance; stats {stats}"
     if strict:
         count = int(finite.sum())
-        assert stats["frac_gt1"] <= max(FRAC_GT1[wmode], 3.0 / max(count, 1)) and stats["max_ulp_noncancelling"] <= MAX_ULP and \
+        assert stats["frac_gt1"] <= max(frac_gt1 if frac_gt1 is not None else FRAC_GT1[wmode], 3.0 / max(count, 1)) and stats["max_ulp_noncancelling"] <= MAX_ULP and \
             (stats["frac_exact"] >= FRAC_EXACT[wmode] or count < 4096), \
             f"{label}: ulp statistics {stats}"
     return stats

@@ -40,6 +40,33 @@ def sample(rng, total, count, always=()):
     return np.array(sorted(rows), dtype=np.int64)
 
 
+def tile_positions(rng, total):
+    """One row for every position a token row can take inside the tiled kernels, in every 256-row tile of [0, total): the tile
+    row (256 rows), the wave row wm (64 rows of it), the 32-row MFMA tile of that wave, and the lane half (lanes 0-31 / 32-63 hold
+    rows 8g + 0..3 / 8g + 4..7 of an MFMA tile's accumulator).  16 rows per 256-row tile -- 256 at M = 4096 -- with the register
+    group g and the register i drawn at random.  The narrower tiles (128 / 64 rows per workgroup, 32 per wave) cut the same 256
+    rows into sub-ranges of these positions, so one sample serves every tile kernel.  A fault confined to one (tile row, wave,
+    MFMA tile, lane half) cannot slip between the sampled rows, which a uniform draw of a few dozen rows allows."""
+    rows = []
+    for t in range((total + 255) // 256):
+        for wm in range(4):
+            for tm in range(2):
+                for hi in range(2):
+                    r = 256 * t + 64 * wm + 32 * tm + 8 * int(rng.integers(4)) + 4 * hi + int(rng.integers(4))
+                    if r < total:
+                        rows.append(r)
+    return np.array(sorted(set(rows)), dtype=np.int64)
+
+
+def sample_rows(rng, total, count, always=()):
+    """the token rows a full-shape test compares with the oracle: `count` random rows, the `always` rows, and -- from the sizes
+    that run on the tiled kernels on -- every tile position (tile_positions)"""
+    rows = set(int(r) for r in sample(rng, total, count, always))
+    if total > 64:
+        rows.update(int(r) for r in tile_positions(rng, total))
+    return np.array(sorted(rows), dtype=np.int64)
+
+
 def assert_rows_match_oracle(q_dev, rows, q_ref, widths, label):
     """q_dev: the GPU quantizer's 6-tuple for ALL rows; q_ref: the oracle's 6-tuple for the sampled `rows` only."""
     import torch

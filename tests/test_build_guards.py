@@ -28,11 +28,34 @@ def test_compiler_leaves_the_accumulator_agprs_alone():
     assert not bad, "\n".join(f"{s}: {c}" for s, c in bad[:10])
 
 
-def test_the_build_runs_the_guard():
-    """python -m micromix_amd.build keeps the assembly of mx_gemm256.hip and fails on a violation (micromix_amd/build.py)"""
+VIOLATING = ("_ZN2mm3g6417mx_gemm256_kernelILb0ELb0EEEvNS_8GemmArgsE: ; @x\n"
+             "\tv_mfma_scale_f32_32x32x64_f8f6f4 a[0:15], v[0:7], v[8:11], a[0:15], v3, v4 op_sel_hi:[0,0,0] cbsz:0 blgp:4\n"
+             "\tds_read2st64_b64 a[0:3], v113 offset0:16 offset1:24\n"
+             ".end_amdhsa_kernel\n")
+
+
+def test_the_build_guard_raises_on_a_violating_assembly(tmp_path):
+    """python -m micromix_amd.build feeds the assembly it kept of mx_gemm256.hip through verify_acc_regs, which must raise on a
+    violation and on a file in which the tile kernels were not found (micromix_amd/build.py)"""
     from micromix_amd import build
-    import inspect
-    assert "verify_acc_regs" in inspect.getsource(build.build)
+    with pytest.raises(RuntimeError, match="no device assembly"):
+        build.verify_acc_regs(str(tmp_path))
+    (tmp_path / "mx_gemm256-hip-amdgcn-amd-amdhsa-gfx950.s").write_text(VIOLATING)
+    with pytest.raises(RuntimeError, match="accumulator AGPR"):
+        build.verify_acc_regs(str(tmp_path))
+    (tmp_path / "mx_gemm256-hip-amdgcn-amd-amdhsa-gfx950.s").write_text(VIOLATING.replace("\tds_read2st64_b64 a[0:3], v113 offset0:16 offset1:24\n", ""))
+    with pytest.raises(RuntimeError, match="expected >="):
+        build.verify_acc_regs(str(tmp_path))
+
+
+def test_an_interrupted_build_with_new_flags_is_forced_again(tmp_path, monkeypatch):
+    """the flags stamp is written after the link, not before the first compile"""
+    from micromix_amd import build
+    monkeypatch.setattr(build, "OBJDIR", str(tmp_path))
+    assert build._flags_changed(["-O3"])
+    assert build._flags_changed(["-O3"])            # asking does not write the stamp
+    open(build._flags_stamp(), "w").write("-O3")
+    assert not build._flags_changed(["-O3"]) and build._flags_changed(["-O3", "-DX"])
 
 
 def test_the_guard_itself_detects_a_violation():

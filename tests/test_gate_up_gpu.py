@@ -1,0 +1,171 @@
+"""mm_gate_up_activate (gate_proj + up_proj + silu(gate) * up + the MX quantization for down_proj as one launch; the reference:
+model/qLlamaLayer.py:377-387, mgemm/src/activate.cu:44-202, bindings.cpp:307-334):
+  * byte for byte against this library's own three-op form matmul(gate), matmul(up) -> activate_quantize_x on the same operands
+    (every segment format, both tile kernels, ragged M, the M <= 64 two-launch path, both roundings), at small shapes and at the
+    Llama-3-8B / Qwen2.5-14B MLP shapes with M in {16, 256, 4096};
+  * against the ORACLE chain (oracle GEMM on the oracle-quantized operands -> oracle activate_quantize) with the stated budget of
+    tests/test_direct_quantize_gpu.py for the silu (device exp) -- on rows whose gate / up values the GPU GEMM reproduces bit for bit;
+  * FusedMLP / TPMLP route through it."""
+import numpy as np
+import pytest
+
+from conftest import bits_from_t, make_inputs, t_from_bits, u8
+from gemm_check import check_gemm
+from micromix_amd import _lib, mixedgemm, tp
+from micromix_amd.qlinear import FusedMLP, QLinearLayer
+from model_case import gen_bf16, gen_index, tile_positions
+from oracle import mx_oracle as o
+
+pytestmark = pytest.mark.gpu
+
+
+def _mm(a, b, **kw):
+    return mixedgemm.matmul(a[0], b[0], a[1], b[1], a[2], b[2], a[3], b[3], a[4], b[4], a[5], b[5], **kw)
+
+
+def assert_same_operands(got, want, rows, split, label):
+    """two 6-tuples of quantizer outputs: packed bytes equal everywhere, scale bytes equal wherever a real row owns them"""
+    for i in range(3):
+        assert got[i].shape == want[i].shape, (label, i, got[i].shape, want[i].shape)
+        assert np.array_equal(u8(got[i]), u8(want[i])), f"{label}: packed segment {i} differs ({int((u8(got[i]) != u8(want[i])).sum())} bytes)"
+        if split[i]:
+            offs = o.sf_valid_offsets(rows, split[i])
+            assert got[3 + i].numel() == want[3 + i].numel()
+            assert np.array_equal(u8(got[3 + i])[offs], u8(want[3 + i])[offs]), f"{label}: scale bytes of segment {i} differ"
+
+
+def three_op(qx, qg, qu, dsplit, rounding="reference"):
+    return mixedgemm.activate_quantize_x(_mm(qx, qg, rounding=rounding), _mm(qx, qu, rounding=rounding), *dsplit)
+
+
+# (M, H, I, in_split, down_split): every consumer format in the first and the last tile, both tile kernels (128- and 256-row),
+# ragged M (partial tiles, a second SF atom without rows), the M <= 64 path
+SMALL = [
+    (200, 512, 384, (256, 128, 128), (128, 128, 128)),
+    (256, 384, 768, (128, 128, 128), (512, 128, 128)),
+    (300, 256, 512, (0, 0, 256), (0, 512, 0)),
+    (130, 256, 256, (256, 0, 0), (0, 0, 256)),
+    (65, 640, 1280, (256, 128, 256), (1024, 128, 128)),
+    (3000, 256, 2304, (128, 0, 128), (1024, 768, 512)),      # > 256 tiles of 256 rows: the 256-row kernel, several rounds
+    (40, 384, 512, (128, 128, 128), (256, 128, 128)),        # M <= 64: weight-streaming GEMM + the quantizer on the interleaved scratch
+    (1, 256, 256, (0, 0, 256), (128, 0, 128)),
+]
+
+
+@pytest.mark.parametrize("m,h,i,in_split,dsplit", SMALL, ids=[f"{c[0]}x{c[1]}x{c[2]}" for c in SMALL])
+def test_fused_equals_three_ops(dev, m, h, i, in_split, dsplit):
+    import torch
+    rng = np.random.default_rng(m + h + i)
+    x = t_from_bits(make_inputs(rng, m, h), dev)
+    wg = t_from_bits(make_inputs(rng, i, h, "weight"), dev) * 8          # gate values of a few units: silu away from its linear range
+    wu = t_from_bits(make_inputs(rng, i, h, "weight"), dev) * 8
+    idx = torch.from_numpy(rng.permutation(h).astype(np.int16)).to(dev)
+    qx = mixedgemm.reorder_quantize_x(x, idx, *in_split)
+    qg = mixedgemm.reorder_quantize_w4(wg, idx, *in_split)
+    qu = mixedgemm.reorder_quantize_w4(wu, idx, *in_split)
+    qgu = mixedgemm.interleave_gate_up(qg, qu)
+    back = mixedgemm.deinterleave_gate_up(qgu)
+    assert all(torch.equal(a, b) for a, b in zip(back[0], qg)) and all(torch.equal(a, b) for a, b in zip(back[1], qu))
+    for rounding in ("reference", "fused"):
+        want = three_op(qx, qg, qu, dsplit, rounding)
+        got = mixedgemm.gate_up_activate(qx, qgu, *dsplit, rounding=rounding)
+        assert_same_operands(got, want, m, dsplit, f"{m}x{h}x{i} {rounding}")
+        again = mixedgemm.gate_up_activate(qx, qgu, *dsplit, rounding=rounding)
+        assert all(torch.equal(a, b) for a, b in zip(got[:3], again[:3]))                 # deterministic
+    desc = _lib.load().mm_gate_up_activate_describe(m, i).decode()
+    assert ("act_kernel" in desc) == (m > 64), desc
+
+
+MODELS = [("llama3-8b", 4096, 14336, (2048, 128, 1920), (12288, 1024, 1024)), ("llama3-8b-fp8x", 4096, 14336, (0, 0, 4096), (7168, 512, 6656)),
+          ("qwen2.5-14b", 5120, 13824, (3072, 1024, 1024), (11776, 1024, 1024))]
+
+
+@pytest.mark.parametrize("name,h,i,in_split,dsplit", MODELS, ids=[c[0] for c in MODELS])
+def test_model_mlp_shapes(dev, name, h, i, in_split, dsplit):
+    """Llama-3-8B and Qwen2.5-14B gate/up at M in {16, 256, 4096}: fused == three ops, byte for byte over the whole [M, I] output;
+    and sampled rows (every tile position at M = 4096) against the oracle chain"""
+    import torch
+    rng = np.random.default_rng(h + i)
+    wg, wu = gen_bf16(dev, i, h, 11, "w") * 4, gen_bf16(dev, i, h, 12, "w") * 4
+    idx = gen_index(dev, h, 13)
+    qg = mixedgemm.reorder_quantize_w4(wg, idx, *in_split)
+    qu = mixedgemm.reorder_quantize_w4(wu, idx, *in_split)
+    qgu = mixedgemm.interleave_gate_up(qg, qu)
+    hg, hu = [u8(t) for t in qg], [u8(t) for t in qu]
+    dg, du = o.dequant_operand(hg, "w", "w4"), o.dequant_operand(hu, "w", "w4")
+    for m in (16, 256, 4096):
+        x = gen_bf16(dev, m, h, seed=m + 5)
+        qx = mixedgemm.reorder_quantize_x(x, idx, *in_split)
+        want = three_op(qx, qg, qu, dsplit)
+        got = mixedgemm.gate_up_activate(qx, qgu, *dsplit)
+        assert_same_operands(got, want, m, dsplit, f"{name} M={m}")
+        # oracle chain on sampled rows
+        rows = tile_positions(rng, m)[::4] if m > 64 else np.arange(m)
+        ridx = torch.from_numpy(rows).to(dev)
+        ref_x = o.reorder_quantize(bits_from_t(x[ridx]), u8(idx), *in_split, "x")
+        # the gate / up values inside the fused launch are those of mm_matmul (asserted above through the three-op twin): hold them to
+        # the oracle GEMM here, then the fused launch's codes to the oracle's activation quantizer ON those values (silu budget)
+        g_gpu, u_gpu = bits_from_t(_mm(qx, qg)[ridx]), bits_from_t(_mm(qx, qu)[ridx])
+        check_gemm(g_gpu, ref_x, hg, "reference", label=f"{name} gate M={m}", strict=len(rows) * i >= 4096, wdeq=dg)
+        check_gemm(u_gpu, ref_x, hu, "reference", label=f"{name} up M={m}", strict=len(rows) * i >= 4096, wdeq=du)
+        ref_q = o.activate_quantize(g_gpu, u_gpu, *dsplit)
+        for s in range(3):
+            if not dsplit[s]:
+                continue
+            gq = u8(got[s][ridx])
+            sf = u8(got[3 + s])
+            j = np.arange(dsplit[s] // 32)[None, :]
+            gsf = sf[o.sf_offset(rows[:, None], j, dsplit[s])]
+            wsf = ref_q[3 + s][o.sf_offset(np.arange(len(rows))[:, None], j, dsplit[s])]
+            assert (gsf != wsf).mean() < 1e-3, f"{name} M={m} segment {s}: scale bytes"
+            assert (gq != ref_q[s]).mean() < 1e-3, f"{name} M={m} segment {s}: packed bytes"
+    del wg, wu
+
+
+def test_fused_mlp_module_and_tpmlp(dev):
+    """FusedMLP == gate(x), up(x) -> activate_quantize_x -> matmul(down), bit for bit; TPMLP (world = 1 and every rank of world = 2)
+    runs the fused kernel and keeps its results"""
+    import torch
+    rng = np.random.default_rng(3)
+    m, hid, inter = 192, 512, 2048
+    in_split, down_split = (256, 128, 128), (1024, 512, 512)
+    x = t_from_bits(make_inputs(rng, m, hid), dev)
+    lin = lambda n, k: t_from_bits(make_inputs(rng, n, k, "weight"), dev)
+    wg, wu, wd = lin(inter, hid), lin(inter, hid), lin(hid, inter)
+    idx = torch.from_numpy(rng.permutation(hid).astype(np.int16)).to(dev)
+    with torch.no_grad():
+        lg = torch.nn.Linear(hid, inter, bias=False, dtype=torch.bfloat16, device=dev); lg.weight.copy_(wg)
+        lu = torch.nn.Linear(hid, inter, bias=False, dtype=torch.bfloat16, device=dev); lu.weight.copy_(wu)
+    gate, up = QLinearLayer(lg, in_split[2], in_split[1], idx), QLinearLayer(lu, in_split[2], in_split[1], idx)
+    mlp = FusedMLP(gate, up, wd, down_split)
+    y = mlp(x.reshape(2, m // 2, hid))
+    qh = mixedgemm.activate_quantize_x(gate(x.reshape(1, m, hid))[0], up(x.reshape(1, m, hid))[0], *down_split)
+    qd = mixedgemm.downproj_quantize_w4(wd, *down_split)
+    want = _mm(qh, qd)
+    assert y.shape == (2, m // 2, hid) and torch.equal(y.reshape(m, hid), want)
+    t1 = tp.TPMLP(wg, wu, wd, idx, in_split, down_split, rank=0, world=1)
+    assert t1.fused and torch.equal(t1.partial(t1.quantize_x(x)), _mm(qh, qd, rounding="fused"))
+    total = torch.zeros((m, hid), dtype=torch.float32, device=dev)
+    for r in range(2):
+        tr = tp.TPMLP(wg, wu, wd, idx, in_split, down_split, rank=r, world=2)
+        total += tr.partial(tr.quantize_x(x), fp32=True)
+    full = _mm(qh, qd, rounding="fused").float()
+    assert float((total - full).abs().max()) <= 2.0 ** -8 * float(full.abs().max()) + 1e-3
+
+
+def test_errors(dev):
+    import torch
+    x = torch.zeros((128, 256), dtype=torch.bfloat16, device=dev)
+    idx = torch.arange(256, dtype=torch.int16, device=dev)
+    qx = mixedgemm.reorder_quantize_x(x, idx, 128, 0, 128)
+    w = torch.zeros((256, 256), dtype=torch.bfloat16, device=dev)
+    q4 = mixedgemm.reorder_quantize_w4(w, idx, 128, 0, 128)
+    qgu = mixedgemm.interleave_gate_up(q4, q4)
+    with pytest.raises(RuntimeError, match="Value error in run_activate_quantize_x"):
+        mixedgemm.gate_up_activate(qx, qgu, 128, 0, 0)                 # does not sum to I
+    with pytest.raises(RuntimeError, match="interleaved fp4 gate/up"):
+        mixedgemm.gate_up_activate(qx, mixedgemm.interleave_gate_up(*[mixedgemm.reorder_quantize_w(w, idx, 128, 0, 128)] * 2), 128, 0, 128)
+    out = mixedgemm.gate_up_activate(qx, qgu, 256, 0, 0)
+    assert out[0].shape == (128, 128) and out[2].shape == (128, 0)
+    assert int(u8(out[0]).max()) == 0                                   # silu(0) * 0 = 0 -> fp4 code 0
+    assert int(u8(out[3])[o.sf_valid_offsets(128, 256)].min()) == 127  # empty block: scale 1.0 (activate.cu:117-120), not 0.5

@@ -1,81 +1,9 @@
-"""Build-time guard for the tile kernels of mx_gemm256.hip: their fp32 accumulators live in AGPRs a[0 : NACC-1] that only the inline
-asm touches (MFMAs, v_accvgpr_read/write) -- the compiler sees them as clobbered, not as live, so under register pressure it may
-allocate a temporary there between two asm statements (it did: `ds_read2st64_b64 a[0:3]` in the 64x128 matching-precision kernel
-while the 4-wave tiles still kept their accumulators this way, which corrupted results; they now leave them to the compiler).  This script compiles the file to assembly and fails if any instruction other than the inline asm's own
-names an accumulator register of its kernel.  python tools/check_acc_regs.py  (exit code 1 on a violation)"""
-import os, re, subprocess, sys, tempfile
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-NACC = {"g256": 128, "g128": 64, "g64": 32, "g32": 0, "g32n": 0}   # the 4-wave tiles leave their accumulators to the compiler
-ASM_OWN = re.compile(r"^\s*(v_mfma_scale_f32_32x32x64_f8f6f4|v_accvgpr_read_b32|v_accvgpr_write_b32)\b")
-
-
-def agprs(line):
-    """AGPR indices named by an instruction line (single registers a5 / a[5] and tuples a[0:3])"""
-    out = []
-    for m in re.finditer(r"\ba\[(\d+):(\d+)\]", line):
-        out += list(range(int(m.group(1)), int(m.group(2)) + 1))
-    for m in re.finditer(r"\ba\[(\d+)\]|\ba(\d+)\b", line):
-        out.append(int(m.group(1) or m.group(2)))
-    return out
-
-
-EXPECTED_KERNELS = 14   # g256: 2 + 2 grouped; g128: 2 + 2 split-K + 2 grouped; g64: 2 + 2 grouped
-
-
-def check(asm_text):
-    """violations only (see check_counted)"""
-    return check_counted(asm_text)[0]
-
-
-def check_counted(asm_text):
-    """(violations, symbols of the kernels with asm-owned accumulators that were examined).  A caller must also require
-    len(examined) >= EXPECTED_KERNELS: a name-mangling change would otherwise make the check pass with nothing examined."""
-    bad, examined = [], []
-    for m in re.finditer(r"^(_ZN2mm\d(g(?:256|128|64|32n|32))(?:17|25)mx_gemm256_(?:grouped_)?kernel\w*):[^\n]*\n(.*?)\.end_amdhsa_kernel",
-                         asm_text, re.S | re.M):
-        sym, ns, body = m.group(1), m.group(2), m.group(3)
-        n = NACC[ns]
-        if n:
-            examined.append(sym)
-        for line in body.split("\n"):
-            code = line.split(";")[0]
-            if not code.strip() or code.strip().startswith("."):
-                continue
-            regs = [r for r in agprs(code) if r < n]
-            if not regs:
-                continue
-            own = ASM_OWN.match(code) is not None
-            # the asm's own accumulator accesses use the bracket form a[i] / a[i:j]; a compiler-generated accvgpr move prints a5
-            if own and not re.search(r"\ba\d+\b", code):
-                continue
-            bad.append((sym, code.strip()))
-    return bad, examined
-
-
-def verify(asm_text):
-    """raises RuntimeError on a violation or when fewer kernels than expected were found; returns the number examined"""
-    bad, examined = check_counted(asm_text)
-    if bad:
-        raise RuntimeError("hipcc allocated a temporary in an accumulator AGPR of a tile kernel (results would be corrupted):\n" +
-                           "\n".join(f"  {s}: {c}" for s, c in bad[:10]))
-    if len(examined) < EXPECTED_KERNELS:
-        raise RuntimeError(f"accumulator-register check found {len(examined)} tile kernels, expected >= {EXPECTED_KERNELS} "
-                           "(kernel names changed? update tools/check_acc_regs.py)")
-    return len(examined)
-
-
-def main():
-    with tempfile.TemporaryDirectory() as tmp:
-        src = os.path.join(ROOT, "micromix_amd", "csrc", "mx_gemm256.hip")
-        cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-fno-gpu-rdc", "-S", "--cuda-device-only",
-               src, "-o", os.path.join(tmp, "k.s")] + sys.argv[1:]
-        subprocess.run(cmd, check=True, cwd=tmp)
-        bad, examined = check_counted(open(os.path.join(tmp, "k.s")).read())
-    for sym, code in bad[:20]:
-        print(f"accumulator register used by the compiler in {sym}: {code}")
-    print(f"{len(bad)} violation(s) in {len(examined)} tile kernels with asm-owned accumulators (expected >= {EXPECTED_KERNELS})")
-    return 1 if bad or len(examined) < EXPECTED_KERNELS else 0
-
+"""Command-line front end of micromix_amd/_check_acc_regs.py (the accumulator-register guard of the tile kernels):
+python tools/check_acc_regs.py [-DFLAG ...]  -- exit code 1 on a violation."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from micromix_amd._check_acc_regs import *   # noqa: F401,F403  (tests and tools import check / check_counted / verify from here)
+from micromix_amd._check_acc_regs import main
 
 if __name__ == "__main__":
     sys.exit(main())
