@@ -88,10 +88,10 @@ def synth_inputs(seed=0, m=M, n=N, k=K):
 
 
 def cpu_baseline(x, w, idx, budget_s=18.0):
-    """the CPU port of QLinearLayer.forward for N = K = 4096 at M in {1, 128, 2048} -- oracle
+    """the CPU port of QLinearLayer.forward for N = K = 4096 at M in {1, 128, 2048, 4096} -- oracle
     quantize-x (numpy) + dequantise + fp32 torch.matmul on all host cores + bf16 rounding after each segment (the reference's
     rounding order); the weight is packed AND dequantised once outside the timed region (a CPU fake-quant layer would hold
-    it that way).  Median of >= 3 repeats after one warm-up, bounded to ~budget_s of CPU time in all."""
+    it that way).  Median of >= 5 repeats after one warm-up, bounded to ~budget_s of CPU time in all."""
     import torch
     from oracle import mx_oracle as o
     cores = torch.get_num_threads()
@@ -111,22 +111,24 @@ def cpu_baseline(x, w, idx, budget_s=18.0):
         return d
 
     by_rows, spent = {}, 0.0
-    for rows in (1, 128, 2048):
+    for rows in (1, 128, 2048, 4096):
         xb = bits(x[:rows])
         forward(xb)
         ts = []
-        while len(ts) < 3 or (len(ts) < 9 and spent < budget_s * (0.2 if rows < 2048 else 1.0)):
+        # median of >= 5 repeats after one warm-up; more (up to 9) while the CPU-time budget lasts
+        while len(ts) < 5 or (len(ts) < 9 and spent < budget_s * (0.15 if rows < 2048 else 0.6 if rows < 4096 else 1.0)):
             t0 = time.perf_counter()
             forward(xb)
             ts.append(time.perf_counter() - t0)
             spent += ts[-1]
         t = float(np.median(ts))
-        by_rows[str(rows)] = {"ms": round(t * 1e3, 3), "tokens_per_s": round(rows / t, 1), "tflops": round(2.0 * rows * N * K / t / 1e12, 4)}
-    return {"value": by_rows["2048"]["tflops"], "unit": "TFLOP/s", "cores": int(cores), "kind": "port",
-            "tokens_per_s": by_rows["2048"]["tokens_per_s"], "by_rows": by_rows,
-            "sample": f"QLinearLayer.forward port at M in (1, 128, 2048) of the {M} token rows, full N=K=4096: oracle quantize-x + "
-                      f"dequantise + fp32 torch.matmul + bf16 rounding per segment, median of >=3 repeats, {spent:.1f} s of CPU time; "
-                      "`value` is the M=2048 figure"}
+        by_rows[str(rows)] = {"ms": round(t * 1e3, 3), "repeats": len(ts), "tokens_per_s": round(rows / t, 1),
+                              "tflops": round(2.0 * rows * N * K / t / 1e12, 4)}
+    return {"value": by_rows["4096"]["tflops"], "unit": "TFLOP/s", "cores": int(cores), "kind": "port",
+            "tokens_per_s": by_rows["4096"]["tokens_per_s"], "by_rows": by_rows,
+            "sample": f"QLinearLayer.forward port at M in (1, 128, 2048, 4096) token rows, full N=K=4096: oracle quantize-x + "
+                      f"dequantise + fp32 torch.matmul + bf16 rounding per segment, median of >= 5 repeats after one warm-up, "
+                      f"{spent:.1f} s of CPU time; `value` is the M=4096 figure (the headline GEMM's own shape)"}
 
 
 def sample_power(out, delay_s=0.6):
@@ -165,6 +167,140 @@ def sample_power(out, delay_s=0.6):
     t = threading.Thread(target=run, daemon=True)
     t.start()
     return t
+
+
+def llama_layer(dev, lib, mixedgemm, x, steps):
+    """BASELINE.json metric (ii): qLinear tokens/s on the Llama-3-8B shapes -- the seven linears of ONE decoder layer (q, k, v, o, gate,
+    up, down; hidden 4096, kv 1024, intermediate 14336; model/qLlamaLayer.py:265-269,377-387) with the quantizers between them, as this
+    library runs them: q / k / v share one `rmsnorm_quantize_x` and are one GEMM over the concatenated weights (FusedQLinear), gate +
+    up + silu * up + the quantization for down_proj are one launch (`gate_up_activate`).  Attention, rope and the residual adds are
+    outside SURVEY.md section 8 and are NOT in the timed region (o_proj reads a fixed tensor).  Random-init weights, synthetic
+    activations; splits (2048,128,1920) for the hidden inputs and (12288,1024,1024) for down_proj."""
+    import torch
+    H, NKV, I = 4096, 1024, 14336
+    in_split, down_split = (2048, 128, 1920), (12288, 1024, 1024)
+    g = torch.Generator(device=dev).manual_seed(11)
+    rnd = lambda r, c: (torch.randn((r, c), generator=g, device=dev) * 0.02).to(torch.bfloat16)
+    idx = torch.argsort(x.float().abs().mean(0)).to(torch.int16)
+    pack = lambda w: mixedgemm.reorder_quantize_w4(w, idx, *in_split)
+    mm = lambda a, b, **kw: mixedgemm.matmul(a[0], b[0], a[1], b[1], a[2], b[2], a[3], b[3], a[4], b[4], a[5], b[5], **kw)
+    w_qkv = pack(torch.cat([rnd(H, H), rnd(NKV, H), rnd(NKV, H)], 0))
+    w_o = pack(rnd(H, H))
+    pg, pu = pack(rnd(I, H)), pack(rnd(I, H))
+    w_gu = mixedgemm.interleave_gate_up(pg, pu)
+    w_gu_cat = tuple(torch.cat((a, b), 0).contiguous() for a, b in zip(pg, pu))
+    del pg, pu
+    w_down = mixedgemm.downproj_quantize_w4(rnd(H, I), *down_split)
+    normw = torch.ones((H,), dtype=torch.bfloat16, device=dev)
+
+    def prefill(xm, attn):
+        qa = mixedgemm.rmsnorm_quantize_x(xm, normw, 1e-5, idx, *in_split)
+        mm(qa, w_qkv)
+        qo = mixedgemm.reorder_quantize_x(attn, idx, *in_split)
+        o = mm(qo, w_o)
+        qm = mixedgemm.rmsnorm_quantize_x(o, normw, 1e-5, idx, *in_split)
+        qh = mixedgemm.gate_up_activate(qm, w_gu, *down_split)
+        return mm(qh, w_down)
+
+    def decode(xm, attn):
+        m = xm.size(0)
+        if mixedgemm.qlinear_decode_supported(m, H + 2 * NKV, *in_split):
+            mixedgemm.qlinear_decode(xm, idx, *w_qkv, *in_split)          # quantize + GEMM in one launch
+            o = mixedgemm.qlinear_decode(attn, idx, *w_o, *in_split)
+        else:
+            mm(mixedgemm.reorder_quantize_x(xm, idx, *in_split), w_qkv)
+            o = mm(mixedgemm.reorder_quantize_x(attn, idx, *in_split), w_o)
+        qm = mixedgemm.reorder_quantize_x(o, idx, *in_split)
+        qh = mixedgemm.gate_up_activate(qm, w_gu, *down_split)            # M <= 64: GEMM into scratch + the quantizer on it
+        return mm(qh, w_down)
+
+    def measure(fn, xm, attn, reps):
+        for _ in range(3):
+            fn(xm, attn)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < 0.3:
+            fn(xm, attn)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn(xm, attn)
+        torch.cuda.synchronize()
+        t_stream = (time.perf_counter() - t0) / reps
+        t_graph = None
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                fn(xm, attn)
+            torch.cuda.current_stream().wait_stream(side)
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr):
+                for _ in range(reps):
+                    fn(xm, attn)
+            gr.replay()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            gr.replay()
+            torch.cuda.synchronize()
+            t_graph = (time.perf_counter() - t0) / reps
+            del gr
+        except Exception as e:
+            print(f"[bench] hipGraph capture of the decoder layer failed ({e})", file=sys.stderr)
+        return t_stream, t_graph
+
+    out = {"model": "Llama-3-8B decoder layer, linears + quantizers only (attention / rope / residuals outside the hot path, not timed)",
+           "linears": {"q/k/v": [H + 2 * NKV, H], "o": [H, H], "gate/up": [2 * I, H], "down": [H, I]},
+           "in_split": list(in_split), "down_split": list(down_split), "by_rows": {}}
+    flop_per_row = 2.0 * (H * (H + 2 * NKV) + H * H + 2 * I * H + H * I)
+    for m in (4096, 8, 1):
+        xm = x[:m].contiguous()
+        attn = (x[:m] * 0.5).contiguous()
+        fn = prefill if m > 64 else decode
+        ts, tg = measure(fn, xm, attn, max(5, steps if m > 64 else 4 * steps))
+        fused_dec = m <= 64 and bool(mixedgemm.qlinear_decode_supported(m, H + 2 * NKV, *in_split))
+        ent = {"launches_per_layer": 7 if m > 64 else (6 if fused_dec else 8),
+               "us_per_layer_stream": round(ts * 1e6, 1), "us_per_layer_graph": round(tg * 1e6, 1) if tg else None,
+               "tokens_per_s_stream": round(m / ts, 1), "tokens_per_s": round(m / (tg or ts), 1),
+               "tokens_per_s_mode": "one hipGraph of the layer's launches" if tg else "stream launches",
+               "tflops": round(flop_per_row * m / (tg or ts) / 1e12, 2)}
+        out["by_rows"][str(m)] = ent
+    # the MLP at M = 4096 both ways (events around 10 back-to-back repetitions; quantize_x excluded: it is the same launch in both)
+    xm = x[:4096].contiguous()
+    qm = mixedgemm.reorder_quantize_x(xm, idx, *in_split)
+    gu = torch.empty((4096, 2 * I), dtype=torch.bfloat16, device=dev)
+
+    def three_op():
+        mm(qm, w_gu_cat, out=gu)                                          # gate | up as one launch (two separate GEMMs take the same time)
+        qh = mixedgemm.activate_quantize_x(ga, gb, *down_split)           # (reads contiguous copies of the two halves)
+        return mm(qh, w_down)
+
+    mm(qm, w_gu_cat, out=gu)
+    ga, gb = gu[:, :I].contiguous(), gu[:, I:].contiguous()
+
+    def fused():
+        return mm(mixedgemm.gate_up_activate(qm, w_gu, *down_split), w_down)
+
+    def ev_time(fn, reps=10):
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < 0.4:        # the decode-sized measurements above let the clocks drop: settle first
+            fn()
+            torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / reps
+    t3, tf = ev_time(three_op), ev_time(fused)
+    out["mlp_M4096"] = {
+        "three_op_us": round(t3, 1), "fused_us": round(tf, 1),
+        "three_op": "one GEMM over gate | up (N = 28672, bf16 out) -> activate_quantize_x -> down GEMM",
+        "fused": "gate_up_activate (gate + up + silu*up + quantize in one launch) -> down GEMM; bit-identical operands for down_proj",
+        "kernel": lib.mm_gate_up_activate_describe(4096, I).decode(),
+        "hbm_bytes_not_moved": 2 * 2 * 4096 * 2 * I}
+    return out
 
 
 def load_traffic():
@@ -363,6 +499,8 @@ def main():
             "algorithmic_flop_per_launch": flop,
             "algorithmic_bytes_per_launch": M * K + N * K // 2 + (M + N) * K // 32 + 2 * M * N,
             "note": "peak = dense fp8-operand scaled-MFMA rate; A is fp8 so the fp8 rate applies to the whole launch",
+            "pool_spread": "the same binary measures 48.2-53.4 us on this pool's boxes (they hold 1.94-2.11 GHz at the 1400 W cap): "
+                           "round-over-round changes of `frac` below ~8 % on this launch are box variance, not code (`zero_operands` is the box-independent figure)",
             # context, not part of the contract: what a loop of nothing but register-operand fp8 x fp4 MFMAs sustains on this chip
             # at its 1400 W package cap (tools/mfma_energy.py, profiles/r02_mfma_shapes.txt) -- the tiled GEMM runs AT that cap
             # (`power`), see DESIGN.md section 4.2
@@ -517,7 +655,9 @@ def main():
         }
         del bp, ap
 
-        # ---- the other quantizers of the path (section 8f): kernel time and algorithmic bytes against 8 TB/s ----
+        # ---- the other quantizers of the path (section 8f): algorithmic bytes against 8 TB/s, timed BOTH ways -- `kernel_us` = events
+        # attached to each dispatch (the kernel's own duration, what rocprofv3's kernel trace reports), `step_us` = back-to-back launches
+        # between two events (kernel boundaries included: what a caller that queues them pays per launch) ----
         def timed_direct(fn, reps=100):
             assert fn() == 0
             for _ in range(10):
@@ -530,26 +670,31 @@ def main():
             a1.record()
             torch.cuda.synchronize()
             return a0.elapsed_time(a1) * 1e-3 / reps
+
+        def both_ways(fn, byts, reps=100):
+            step = timed_direct(fn, reps)
+            kern = kernel_us(fn, min(reps, 50)) * 1e-6
+            return {"kernel_us": round(kern * 1e6, 2), "step_us": round(step * 1e6, 2), "GBps": round(byts / kern / 1e9, 1),
+                    "frac_of_8TBps": round(byts / kern / 8e12, 4), "step_frac_of_8TBps": round(byts / step / 8e12, 4)}
         quant = {}
         qsplit = (2048, 128, 1920)
         qo2 = mixedgemm.reorder_quantize_x(x, idx, *qsplit)
         out_b = M * (qsplit[0] // 2 + qsplit[1] * 3 // 4 + qsplit[2]) + M * K // 32
         normw = torch.ones((K,), dtype=torch.bfloat16, device=dev)
-        t_rms = timed_direct(lambda: lib.mm_rmsnorm_quantize(x.data_ptr(), normw.data_ptr(), 1e-5, M, K, idx.data_ptr(), *qsplit, 0,
-                                                             *[ptr(t) for t in qo2], sptr))
-        t_reo = timed_direct(lambda: lib.mm_reorder_quantize(x.data_ptr(), M, K, idx.data_ptr(), *qsplit, 0, *[ptr(t) for t in qo2], sptr))
-        for name, t, byts in (("rmsnorm_quantize_x", t_rms, 2 * M * K + out_b + 4 * K), ("reorder_quantize_x", t_reo, 2 * M * K + out_b + 2 * K)):
-            quant[name] = {"rows": M, "K": K, "split": list(qsplit), "kernel_us": round(t * 1e6, 2), "GBps": round(byts / t / 1e9, 1),
-                           "frac_of_8TBps": round(byts / t / 8e12, 4)}
+        quant["rmsnorm_quantize_x"] = dict({"rows": M, "K": K, "split": list(qsplit)}, **both_ways(
+            lambda: lib.mm_rmsnorm_quantize(x.data_ptr(), normw.data_ptr(), 1e-5, M, K, idx.data_ptr(), *qsplit, 0, *[ptr(t) for t in qo2], sptr),
+            2 * M * K + out_b + 4 * K))
+        quant["reorder_quantize_x"] = dict({"rows": M, "K": K, "split": list(qsplit)}, **both_ways(
+            lambda: lib.mm_reorder_quantize(x.data_ptr(), M, K, idx.data_ptr(), *qsplit, 0, *[ptr(t) for t in qo2], sptr), 2 * M * K + out_b + 2 * K))
         inter, asplit = 14336, (12288, 1024, 1024)
         ga = torch.randn((M, inter), device=dev, dtype=torch.float32).to(torch.bfloat16)
         gb = torch.randn((M, inter), device=dev, dtype=torch.float32).to(torch.bfloat16)
         qa = mixedgemm.activate_quantize_x(ga, gb, *asplit)
-        t_act = timed_direct(lambda: lib.mm_activate_quantize(ga.data_ptr(), gb.data_ptr(), M, *asplit, *[ptr(t) for t in qa], sptr), 50)
         act_b = 2 * 2 * M * inter + M * (asplit[0] // 2 + asplit[1] * 3 // 4 + asplit[2]) + M * inter // 32
-        quant["activate_quantize_x"] = {"rows": M, "K": inter, "split": list(asplit), "kernel_us": round(t_act * 1e6, 2),
-                                        "GBps": round(act_b / t_act / 1e9, 1), "frac_of_8TBps": round(act_b / t_act / 8e12, 4)}
-        quant["timing"] = "back-to-back direct C-ABI launches between two events on the launch stream"
+        quant["activate_quantize_x"] = dict({"rows": M, "K": inter, "split": list(asplit)}, **both_ways(
+            lambda: lib.mm_activate_quantize(ga.data_ptr(), gb.data_ptr(), M, *asplit, *[ptr(t) for t in qa], sptr), act_b, 50))
+        quant["timing"] = ("kernel_us: HIP events attached to each dispatch (mm_diag_set_kernel_events), mean; step_us: back-to-back direct "
+                           "C-ABI launches between two events on the launch stream; frac_of_8TBps is the kernel's, step_frac_of_8TBps the step's")
         result["quantizers"] = quant
         del ga, gb, qa, qo2
 
@@ -569,8 +714,8 @@ def main():
             mm(q, b, out)
         settle(fwd, 0.4)
         t_fwd = timed(fwd)
-        fwd_launch = "stream launches"
-        if graph is not None:       # the same K forwards as one hipGraph (as the GEMM steps above)
+        t_fwd_graph = None
+        if graph is not None:       # the same K forwards as one hipGraph, reported BESIDE the stream figure (never instead of it)
             try:
                 gq = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(gq):
@@ -581,9 +726,7 @@ def main():
                 t = time.perf_counter()
                 gq.replay()
                 torch.cuda.synchronize()
-                t_graph = (time.perf_counter() - t) / args.steps
-                if t_graph < t_fwd:
-                    t_fwd, fwd_launch = t_graph, "one hipGraph of K forwards"
+                t_fwd_graph = (time.perf_counter() - t) / args.steps
                 del gq
             except Exception as e:
                 print(f"[bench] hipGraph capture of the forward failed ({e})", file=sys.stderr)
@@ -594,19 +737,24 @@ def main():
         stream = torch.cuda.current_stream().cuda_stream
         # (events around 100 back-to-back launches, as the `quantizers` section: a wall clock around --steps launches charges the final
         # synchronize to them -- with the driver's 20 steps that is ~1.5 us on a 9 us kernel)
-        t_q = timed_direct(lambda: lib.mm_reorder_quantize(x.data_ptr(), M, K, idx.data_ptr(), *SPLIT, 0, pp(qo[0]), pp(qo[1]), pp(qo[2]),
-                                                           pp(qo[3]), pp(qo[4]), pp(qo[5]), stream))
+        q_bytes = 2 * M * K + M * K + M * K // 32 + 2 * K
+        qx_both = both_ways(lambda: lib.mm_reorder_quantize(x.data_ptr(), M, K, idx.data_ptr(), *SPLIT, 0, pp(qo[0]), pp(qo[1]), pp(qo[2]),
+                                                            pp(qo[3]), pp(qo[4]), pp(qo[5]), stream), q_bytes)
         bw = mixedgemm.reorder_quantize_w(w, idx, *SPLIT)
         fw = lambda: mm(a, bw, out)
         us_w = kernel_us(fw, args.steps)
-        q_bytes = 2 * M * K + M * K + M * K // 32 + 2 * K
         result["qlinear"] = {
-            "tokens_per_s": round(M / t_fwd, 1), "forward_us": round(t_fwd * 1e6, 2), "forward_launch": fwd_launch,
-            "quantize_x_kernel_us": round(t_q * 1e6, 2), "quantize_x_timing": "events around 100 back-to-back direct C-ABI launches",
-            "quantize_x_GBps": round(q_bytes / t_q / 1e9, 1),
-            "quantize_x_frac_of_8TBps": round(q_bytes / t_q / 8e12, 4),
+            "tokens_per_s": round(M / t_fwd, 1), "forward_us": round(t_fwd * 1e6, 2), "forward_launch": "stream launches (quantize_x + matmul per forward)",
+            "forward_us_graph": round(t_fwd_graph * 1e6, 2) if t_fwd_graph else None,
+            "tokens_per_s_graph": round(M / t_fwd_graph, 1) if t_fwd_graph else None,
+            "quantize_x_kernel_us": qx_both["kernel_us"], "quantize_x_step_us": qx_both["step_us"],
+            "quantize_x_timing": "kernel_us: events attached to each dispatch; step_us: 100 back-to-back direct C-ABI launches between two events",
+            "quantize_x_GBps": qx_both["GBps"], "quantize_x_frac_of_8TBps": qx_both["frac_of_8TBps"],
+            "quantize_x_step_frac_of_8TBps": qx_both["step_frac_of_8TBps"],
             "gemm_w_mode_kernel_us": round(us_w, 2), "gemm_w_mode_tflops": round(flop / us_w / 1e6, 2),
         }
+        del bw
+        result["llama_layer"] = llama_layer(dev, lib, mixedgemm, x, args.steps)
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(x_cpu, w_cpu, idx_cpu)
     if world > 1:

@@ -254,7 +254,8 @@ const char *mm_test_function(void);
  * no result).  THREAD-LOCAL: it affects only launches made by the calling thread.
  *
  * mm_diag_set_kernel_events: while a pair of hipEvent_t is registered, every tiled-GEMM launch (M > 64, and the M > 32 shapes that
- *   run on tiles) of this thread attaches them to its own dispatch (hipExtLaunchKernel start/stop events), so hipEventElapsedTime
+ *   run on tiles; mm_gate_up_activate's fused launch) and every quantizer launch (mm_reorder_quantize, mm_rmsnorm_quantize,
+ *   mm_activate_quantize, mm_downproj_quantize) of this thread attaches them to its own dispatch (hipExtLaunchKernel start/stop events), so hipEventElapsedTime
  *   gives the kernel's duration as rocprofv3 reports it, without the launch gap that events recorded around the call include.
  *   NULL, NULL disables.  Host-side only: the kernels are the same with and without it.
  *

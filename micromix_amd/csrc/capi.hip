@@ -9,7 +9,8 @@
 
 static thread_local char g_last_error[256] = "";
 // measurement hooks, per calling thread (see mm_diag_set_kernel_events / mm_diag_set_clock_buffer in the header)
-static thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
+static thread_local mm::DiagEvents g_ev = {nullptr, nullptr};
+namespace mm { DiagEvents &diag_events() { return g_ev; } }
 static thread_local unsigned long long *g_clock_buf = nullptr;
 
 static int fail_hip(hipError_t e, const char *where) {
@@ -190,8 +191,8 @@ int mm_matmul_ws(const uint8_t *AN, const uint8_t *BN, const uint8_t *AS, const 
     a.out_f32 = out_f32 ? 1 : 0;
     a.act = 0;
     a.clock_out = g_clock_buf;
-    a.ev_start = g_ev_start;
-    a.ev_stop = g_ev_stop;
+    a.ev_start = g_ev.start;
+    a.ev_stop = g_ev.stop;
     a.ws = (float *)workspace;
     a.ws_bytes = workspace ? workspace_bytes : 0;
     a.splits = 0;
@@ -262,8 +263,8 @@ int mm_gate_up_activate(const uint8_t *AN, const uint8_t *BN, const uint8_t *AS,
     a.act_o[0] = oN; a.act_o[1] = oS; a.act_o[2] = oO;
     a.act_sf[0] = sfN; a.act_sf[1] = sfS; a.act_sf[2] = sfO;
     a.clock_out = nullptr;
-    a.ev_start = g_ev_start;
-    a.ev_stop = g_ev_stop;
+    a.ev_start = g_ev.start;
+    a.ev_stop = g_ev.stop;
     a.ws = nullptr; a.ws_bytes = 0; a.splits = 0; a.tickets = nullptr; a.tickets_zeroed = 0;
     a.n_tile0 = a.n_tiles = 0;
     a.force_split = 0;
@@ -407,8 +408,8 @@ int mm_matmul_grouped(const mm_group *groups, int ngroups, int N, int KN, int KS
 }
 
 int mm_diag_set_kernel_events(void *start_event, void *stop_event) {
-    g_ev_start = (hipEvent_t)start_event;
-    g_ev_stop = (hipEvent_t)stop_event;
+    g_ev.start = (hipEvent_t)start_event;
+    g_ev.stop = (hipEvent_t)stop_event;
     return MM_OK;
 }
 

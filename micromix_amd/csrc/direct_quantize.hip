@@ -183,7 +183,7 @@ hipError_t launch_direct_quantize(const void *A, const void *B, int rows, int KN
     // mode 3 = mode 0 on the interleaved [rows, 2 K] layout (A = the matrix, B = A + 128 elements; the caller passes both)
     auto kern = mode == 0 ? direct_quantize_kernel<0> : mode == 1 ? direct_quantize_kernel<1> : mode == 2 ? direct_quantize_kernel<2>
                                                                                                            : direct_quantize_kernel<0, true>;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, stream, (const uint16_t *)A, (const uint16_t *)B, rows, KN, KS, KO,
+    MM_LAUNCH(kern, dim3((unsigned)blocks), dim3(256), 0, stream, (const uint16_t *)A, (const uint16_t *)B, rows, KN, KS, KO,
                        oN, oS, oO, sfN, sfS, sfO);
     return hipGetLastError();
 }

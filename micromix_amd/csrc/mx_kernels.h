@@ -1,6 +1,7 @@
 // Host-side launch interface between capi.hip and the kernel translation units.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include <atomic>
@@ -52,6 +53,20 @@ struct OccupancyCache {
         return per_cu;
     }
 };
+
+// Measurement hook (mm_diag_set_kernel_events): the calling thread's pair of events, both null unless registered.  The quantizer
+// launchers (MM_LAUNCH) and the tiled GEMM (GemmArgs::ev_start / ev_stop) attach them to their dispatch, so that their elapsed time is
+// the kernel's own duration -- what rocprofv3's kernel trace reports -- without the launch gap that events around a call include.
+struct DiagEvents { hipEvent_t start, stop; };
+DiagEvents &diag_events();     // thread-local, defined in capi.hip
+#define MM_LAUNCH(kern, grid, block, lds, stream, ...)                                                                      \
+    do {                                                                                                                   \
+        const mm::DiagEvents &ev_ = mm::diag_events();                                                                     \
+        if (ev_.start != nullptr && ev_.stop != nullptr)                                                                   \
+            hipExtLaunchKernelGGL(kern, grid, block, lds, stream, ev_.start, ev_.stop, 0, __VA_ARGS__);                    \
+        else                                                                                                               \
+            hipLaunchKernelGGL(kern, grid, block, lds, stream, __VA_ARGS__);                                               \
+    } while (0)
 
 constexpr int MM_MAX_SPLITS = 16;   // in-kernel split-K: splits per tile
 

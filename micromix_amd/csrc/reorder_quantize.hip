@@ -191,7 +191,7 @@ hipError_t launch_reorder_quantize(const void *src, int rows, int K, const int16
     // one row per workgroup with the occupancy limited to 12 / 8 / 4 workgroups per CU, so that rounds of workgroups overlap
     // their load / gather / store phases: 11.3 / 11.4 / 13.7 us)
     blocks = rows < blocks ? rows : blocks;
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds, stream, (const uint16_t *)src, rows, K, idx, KN, KS, KO, oN,
+    MM_LAUNCH(kern, dim3(blocks), dim3(threads), lds, stream, (const uint16_t *)src, rows, K, idx, KN, KS, KO, oN,
                        oS, oO, sfN, sfS, sfO);
     return hipGetLastError();
 }

@@ -367,7 +367,7 @@ hipError_t launch_rmsnorm_quantize(const void *src, const void *weight, float ep
     const int cus = device_cus();
     int blocks = cus * per_cu;
     blocks = rows < blocks ? rows : blocks;
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds, stream, (const uint16_t *)src, (const uint16_t *)weight, eps, rows,
+    MM_LAUNCH(kern, dim3(blocks), dim3(threads), lds, stream, (const uint16_t *)src, (const uint16_t *)weight, eps, rows,
                        K, idx, KN, KS, KO, oN, oS, oO, sfN, sfS, sfO);
     return hipGetLastError();
 }
