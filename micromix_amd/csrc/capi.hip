@@ -262,7 +262,7 @@ int mm_gate_up_activate(const uint8_t *AN, const uint8_t *BN, const uint8_t *AS,
     a.act_K[0] = DN; a.act_K[1] = DS; a.act_K[2] = DO;
     a.act_o[0] = oN; a.act_o[1] = oS; a.act_o[2] = oO;
     a.act_sf[0] = sfN; a.act_sf[1] = sfS; a.act_sf[2] = sfO;
-    a.clock_out = nullptr;
+    a.clock_out = g_clock_buf;
     a.ev_start = g_ev.start;
     a.ev_stop = g_ev.stop;
     a.ws = nullptr; a.ws_bytes = 0; a.splits = 0; a.tickets = nullptr; a.tickets_zeroed = 0;
