@@ -142,6 +142,21 @@ namespace mm {
 #undef MM_ACC
 #undef MM_MAX_STAGES
 #undef MM_LDS_BUDGET
+#define MM_NS g16
+#define MM_MAX_STAGES 3
+#define MM_LDS_BUDGET (160 * 1024)
+#define MM_WM 1
+#define MM_TM 1
+#define MM_TN 1
+#define MM_ACC MM_ACC_CLOBBER32
+#include "mx_gemm_tile.inc"
+#undef MM_NS
+#undef MM_WM
+#undef MM_TM
+#undef MM_TN
+#undef MM_ACC
+#undef MM_MAX_STAGES
+#undef MM_LDS_BUDGET
 
 
 // ---------------------------------------------------------------------------------------------------------
@@ -356,10 +371,10 @@ static hipError_t launch_tile(KernelT kern, DynamicLdsOnce &attr, int lds_bytes,
 }
 
 // Which kernel(s) a problem runs on: decided once here, used by the launcher and by mm_matmul_describe.
-enum TileKind { TK_SPLITK, TK_SMALL_SPLIT, TK_G64, TK_G256_TAIL, TK_G256, TK_G128, TK_G32, TK_G32N };
+enum TileKind { TK_SPLITK, TK_SMALL_SPLIT, TK_G64, TK_G256_TAIL, TK_G256, TK_G128, TK_G32, TK_G32N, TK_G16 };
 struct TilePlan {
     TileKind kind;
-    int tn, tiles256, tiles128, tiles64, tiles32, tiles32n, tm256, tm128, tail_cols;
+    int tn, tiles256, tiles128, tiles64, tiles32, tiles32n, tiles16, tm256, tm128, tail_cols;
     int splits, split_first[4];
     SmallSplit small;
 };
@@ -374,6 +389,7 @@ static TilePlan plan_tiles(int M, int N, const int K[3], bool w4, bool have_ws, 
     p.tiles64 = p.tm128 * ((N + 127) / 128);
     p.tiles32 = ((M + 63) / 64) * ((N + 127) / 128);
     p.tiles32n = ((M + 63) / 64) * ((N + 63) / 64);
+    p.tiles16 = ((M + 31) / 32) * ((N + 63) / 64);
     if (have_ws) {
         p.small = tickets_zeroed ? plan_small_split(M, N, K, force_split) : SmallSplit{0, 0, 0};
         if (p.small.kind && p.small.tiles * 4 <= (int)MM_TICKET_BYTES && small_split_bytes(p.small) <= ws_bytes) {
@@ -392,8 +408,15 @@ static TilePlan plan_tiles(int M, int N, const int K[3], bool w4, bool have_ws, 
     static const int force = env_int("MICROMIX_GEMM_TILE", 0);   // kernel-developer override: 256, 128 or 64
     static const int tail_split = env_int("MICROMIX_GEMM_TAIL", 1);
     const int cus = device_cus();
-    if (force == 32 || force == 33) {
-        p.kind = force == 32 ? TK_G32 : TK_G32N;
+    if (force == 32 || force == 33 || force == 16) {
+        p.kind = force == 32 ? TK_G32 : force == 33 ? TK_G32N : TK_G16;
+        return p;
+    }
+    // 64 x 64 tiles on at most half of the CUs (q/o at M <= 128: 128 tiles): 32 x 64 tiles (two compute + two loader waves) double the
+    // workgroups; every workgroup then walks its K with half the LDS traffic per slab (round 4, tools/time_cases.py)
+    static const int use16 = env_int("MICROMIX_GEMM_TILE16", 1);
+    if (force == 0 && use16 && 2 * p.tiles32n <= cus && p.tiles16 <= 2 * cus) {
+        p.kind = TK_G16;
         return p;
     }
     // Fewer than a CU's worth of 128-row tiles: the 4-wave tiles (64 rows, loader / compute waves, see mx_gemm_tile.inc) fill more
@@ -442,6 +465,15 @@ bool mx_gemm_small_m_uses_tiles(int M, int N, const int K[3], bool w4, size_t ws
     if (M > 16 && M <= 32) return (N + 31) / 32 > 3 * device_cus();
     if (M <= 32 || M > 64) return M > 64;
     if ((N + 31) / 32 > device_cus()) return true;
+    // 32 < M <= 64 on one round of 32 x 64 tiles (round 4; tools/_job history in profiles/r04_small_tiles.txt, (2048,128,1920), us):
+    // a workgroup of those tiles walks K = 4096 in ~9.8 us however many of them there are, the weight-streaming kernel needs
+    // 9.2 / 9.7 / 10.0 / 12.2 at M = 33 / 40 / 48 / 64 for N <= 4096 and 10.4 ... 12.3 at N = 6144 (more than half a round of its
+    // 32-feature workgroups).  So: M > 48 always, smaller M from N / 32 > CUs / 2 on.
+    {
+        static const int small16 = env_int("MICROMIX_SMALL_M_TILE16", 1);
+        const int t16 = ((M + 31) / 32) * ((N + 63) / 64);
+        if (small16 && t16 <= device_cus() && (M > 48 || 2 * ((N + 31) / 32) > device_cus())) return true;
+    }
     if (ws_bytes == 0) return false;
     const size_t need = mx_gemm_workspace_bytes(M, N, K, w4, force_split, false);   // (the in-kernel split starts above M = 64)
     return need > 0 && need <= ws_bytes;
@@ -457,6 +489,7 @@ const char *describe_mx_gemm256(int M, int N, const int K[3], bool w4, size_t ws
         case TK_G64: snprintf(buf, sizeof(buf), "mm::g64::mx_gemm256_kernel<%s,false> x %d workgroups (128x128 tiles)", w, p.tiles64); break;
         case TK_G32: snprintf(buf, sizeof(buf), "mm::g32::mx_gemm256_kernel<%s,false> x %d workgroups (64x128 tiles)", w, p.tiles32); break;
         case TK_G32N: snprintf(buf, sizeof(buf), "mm::g32n::mx_gemm256_kernel<%s,false> x %d workgroups (64x64 tiles)", w, p.tiles32n); break;
+        case TK_G16: snprintf(buf, sizeof(buf), "mm::g16::mx_gemm256_kernel<%s,false> x %d workgroups (32x64 tiles)", w, p.tiles16); break;
         case TK_G256_TAIL: snprintf(buf, sizeof(buf), "mm::g256::mx_gemm256_kernel<%s,false> x %d workgroups (256x256 tiles) + mm::g128::mx_gemm256_kernel<%s,false> x %d (last %d tile columns as 128x256 tiles)", w, p.tm256 * (p.tn - p.tail_cols), w, p.tm128 * p.tail_cols, p.tail_cols); break;
         case TK_G256: snprintf(buf, sizeof(buf), "mm::g256::mx_gemm256_kernel<%s,false> x %d workgroups (256x256 tiles)", w, p.tiles256); break;
         default: snprintf(buf, sizeof(buf), "mm::g128::mx_gemm256_kernel<%s,false> x %d workgroups (128x256 tiles)", w, p.tiles128); break;
@@ -523,6 +556,11 @@ hipError_t launch_mx_gemm256(const GemmArgs &a, bool w4, hipStream_t stream) {
         case TK_G32N:
             if (w4) return launch_tile(g32n::mx_gemm256_kernel<true, false>, done[10], g32n::Lds<true>::TOTAL, p.tiles32n, g32n::NTHREADS, a, stream);
             return launch_tile(g32n::mx_gemm256_kernel<false, false>, done[11], g32n::Lds<false>::TOTAL, p.tiles32n, g32n::NTHREADS, a, stream);
+        case TK_G16: {
+            static DynamicLdsOnce d16[2];
+            if (w4) return launch_tile(g16::mx_gemm256_kernel<true, false>, d16[0], g16::Lds<true>::TOTAL, p.tiles16, g16::NTHREADS, a, stream);
+            return launch_tile(g16::mx_gemm256_kernel<false, false>, d16[1], g16::Lds<false>::TOTAL, p.tiles16, g16::NTHREADS, a, stream);
+        }
         case TK_G256_TAIL: {
             const int c = p.tail_cols;
             GemmArgs lo = a, hi = a;

@@ -43,6 +43,7 @@ def test_matmul_describe_names_the_dispatch():
     assert d(0, 4096, 0, 0, 4096, 1, 0, 0) == "none" and d(4096, 4096, 100, 0, 0, 1, 0, 0) == "none"
     assert "split-K" in d(192, 256, 12288, 1024, 1024, 1, _lib.MM_SPLIT_K_ALWAYS, 1 << 30)
     # few tiles: the 4-wave 64-row tiles while they fit one round of workgroups, then 128 x 128, 128 x 256
+    assert "g16" in d(128, 4096, 0, 0, 4096, 1, 0, 0) and "256 workgroups (32x64 tiles)" in d(128, 4096, 0, 0, 4096, 1, 0, 0)
     assert "g32n" in d(256, 4096, 0, 0, 4096, 1, 0, 0) and "256 workgroups (64x64 tiles)" in d(256, 4096, 0, 0, 4096, 1, 0, 0)
     assert "g32::" in d(512, 4096, 0, 0, 4096, 1, 0, 0) and "(64x128 tiles)" in d(512, 4096, 0, 0, 4096, 1, 0, 0)
     assert "g64" in d(1024, 4096, 0, 0, 4096, 1, 0, 0) and "g128" in d(2048, 4096, 0, 0, 4096, 1, 0, 0)

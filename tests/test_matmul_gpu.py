@@ -443,6 +443,8 @@ def test_poisoned_ticket_and_ws_reset(dev):
 # one problem per tile kernel of mx_gemm256.hip (the dispatch is asserted, so a change of plan_tiles cannot silently drop one):
 # ragged M and N, all three segments, both weight modes; oracle on a row sample over every column
 TILE_KERNELS = [
+    # (and 32 < M <= 64 from M > 48 / N > 4096 on, instead of the weight-streaming kernel)
+    ("g16", "32x64", 100, 4090), ("g16", "32x64", 128, 4000), ("g16", "32x64", 64, 4096), ("g16", "32x64", 40, 6144),     # 64 x 64 tiles would fill at most half of the CUs: 32 x 64 tiles
     ("g32n", "64x64", 250, 4000), ("g32n", "64x64", 50, 8230),   # 32 < M <= 64 and more than a round of skinny workgroups: tiles
     ("g32", "64x128", 500, 4090), ("g64", "128x128", 700, 4090),
     ("g128", "128x256", 1500, 4000), ("g256", "256x256", 4000, 4090),
