@@ -21,11 +21,11 @@
 //    directly: one dword per lane holds the 4 block scales of its row for a 128-K slab.
 //
 // Kernels by token count M:
-//  * M <= 64 : mx_gemm_skinny.hip -- weight-streaming, 32 features per workgroup, K split over the 8 waves (for 32 < M <= 64 only
-//                                    while N / 32 workgroups fit one round and K is not split, for 16 < M <= 32 while they fit
-//                                    three rounds: mx_gemm_small_m_uses_tiles)
+//  * M <= 64 : mx_gemm_skinny.hip -- weight-streaming, 32 features per workgroup, K split over the 8 waves (for 48 < M <= 64 only
+//                                    when no round of 32 x 64 tiles fits, for 32 < M <= 48 while N / 32 workgroups fit half a round
+//                                    and K is not split, for M <= 32 while they fit three rounds: mx_gemm_small_m_uses_tiles)
 //  * M  > 64 : mx_gemm256.hip     -- LDS-DMA pipelined 256x256 tiles when they fill the chip, else 128x256 / 128x128 tiles,
-//                                    64x128 / 64x64 tiles with loader and compute waves for the smallest launches, or split-K
+//                                    64x128 / 64x64 / 32x64 tiles with loader and compute waves for the smallest launches, or split-K
 //                                    through a caller-provided workspace (plan_tiles / plan_splits, fitted to measurements)
 #include <stdlib.h>
 

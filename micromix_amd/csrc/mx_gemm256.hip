@@ -415,7 +415,7 @@ static TilePlan plan_tiles(int M, int N, const int K[3], bool w4, bool have_ws, 
     // 64 x 64 tiles on at most half of the CUs (q/o at M <= 128: 128 tiles): 32 x 64 tiles (two compute + two loader waves) double the
     // workgroups; every workgroup then walks its K with half the LDS traffic per slab (round 4, tools/time_cases.py)
     static const int use16 = env_int("MICROMIX_GEMM_TILE16", 1);
-    if (force == 0 && use16 && 2 * p.tiles32n <= cus && p.tiles16 <= 2 * cus) {
+    if (force == 0 && use16 && p.tiles16 <= 2 * cus && (2 * p.tiles32n <= cus || M <= 32)) {   // (M <= 32: one row of tiles, see mx_gemm_small_m_uses_tiles)
         p.kind = TK_G16;
         return p;
     }
@@ -462,7 +462,9 @@ bool mx_gemm_small_m_uses_tiles(int M, int N, const int K[3], bool w4, size_t ws
     // 16 < M <= 32: only with more than three rounds of 32-feature workgroups (fused gate + up, N = 28672: the 64-row tiles take
     // 19.2-20.0 us at M = 17 / 24 / 32, the weight-streaming kernel 20.7 / 22.1 / 23.9; at N <= 24576 the latter wins or ties:
     // tools/time_skinny_big_n.py, profiles/notes_r03.md section 24)
-    if (M > 16 && M <= 32) return (N + 31) / 32 > 3 * device_cus();
+    // (round 4: with the 32 x 64 tiles also M <= 16 -- N = 28672, us at M = 1 / 8 / 16 / 24 / 32: weight-streaming or 64 x 64 tiles
+    // 17.4 / 18.6 / 20.3 / 18.6 / 18.6, 32 x 64 tiles 16.7 / 16.8 / 16.7 / 16.9 / 16.9; at N <= 14336 the weight-streaming kernel wins by 1-4 us)
+    if (M <= 32) return (N + 31) / 32 > 3 * device_cus();
     if (M <= 32 || M > 64) return M > 64;
     if ((N + 31) / 32 > device_cus()) return true;
     // 32 < M <= 64 on one round of 32 x 64 tiles (round 4; tools/_job history in profiles/r04_small_tiles.txt, (2048,128,1920), us):

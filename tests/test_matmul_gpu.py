@@ -515,7 +515,8 @@ def _boundary_shapes():
         for n in (40, 264, 4104, 8200):
             shapes.append((m, n))
     shapes += [(256, 4096), (257, 4096), (512, 4096), (513, 4100), (385, 4096), (1025, 1000), (640, 2060)]
-    shapes += [(16, 24608), (17, 24608), (32, 24608), (17, 24576)]   # 16 < M <= 32 and more than three rounds of skinny workgroups: 64-row tiles
+    # M <= 32 and more than three rounds of skinny workgroups (fused gate + up): 32 x 64 tiles; (17, 24576) stays on the skinny kernel
+    shapes += [(1, 24608), (8, 24608), (16, 24608), (17, 24608), (32, 24608), (17, 24576)]
     return shapes
 
 
