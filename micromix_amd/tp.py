@@ -120,6 +120,11 @@ class _HipOps:
         return mixedgemm.interleave_gate_up(gate, up)
 
     @staticmethod
+    def deinterleave_gate_up(packed):
+        from . import mixedgemm
+        return mixedgemm.deinterleave_gate_up(packed)
+
+    @staticmethod
     def gate_up_activate(a, b, kn, ks, ko):
         """gate, up, silu(gate) * up and the quantization for down_proj as one launch (mm_gate_up_activate)"""
         from . import mixedgemm
@@ -335,8 +340,7 @@ class TPMLP:
             self.packed_down = self.ops.downproj_quantize_w4(w_down[:, sel].contiguous(), *self.widths)
 
     def _split_gate_up(self):
-        from . import mixedgemm
-        return mixedgemm.deinterleave_gate_up(self.packed_gate_up)
+        return self.ops.deinterleave_gate_up(self.packed_gate_up)
 
     @property
     def packed_gate(self):
