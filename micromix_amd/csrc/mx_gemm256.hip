@@ -36,6 +36,9 @@
 #ifndef MM_FP4_KD256
 #define MM_FP4_KD256 1  // fp4 x fp4 segment on 256-deep slabs (whole cache lines per row); 0 = 128-deep slabs like the other segments
 #endif
+#ifndef MM_PRIO
+#define MM_PRIO 1        // s_setprio for waves 4-7 of the 8-wave tiles (mx_gemm_tile.inc, tile_body); 0 = none
+#endif
 #ifndef MM_XREG
 #define MM_XREG 0   // bit 0: activations of the 256-row tile's fp4 x fp4 segment through registers (mx_gemm_tile.inc, "Hybrid")
 #endif
