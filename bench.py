@@ -624,6 +624,36 @@ def main():
                              "note": "448 feature blocks walked by one workgroup per CU (the activation row is quantized once per workgroup)"}
         del bg
         result["decode"] = dec
+        # ---- the largest GEMMs of a decoder layer at M = 16 / 32 / 64 (speculative / batched decode): weight bytes against 8 TB/s ----
+        sm = {}
+        for name, nn_, kk_, sp in (("gate_up", 14336, K, fsplit), ("gate_up_fused", 28672, K, fsplit), ("down", 4096, 14336, (12288, 1024, 1024))):
+            xc, wc, ic = synth_inputs(1, 64, nn_, kk_)
+            xs, ws, ids = xc.to(dev), wc.to(dev), ic.to(dev)
+            bs_ = mixedgemm.reorder_quantize_w4(ws, ids, *sp)
+            del ws
+            for m_ in (16, 32, 64):
+                as_ = mixedgemm.reorder_quantize_x(xs[:m_].contiguous(), ids, *sp)
+                os_ = torch.empty((m_, nn_), dtype=torch.bfloat16, device=dev)
+                pa = [t.data_ptr() if t.numel() else None for t in (as_[0], bs_[0], as_[1], bs_[1], as_[2], bs_[2], as_[3], bs_[3], as_[4], bs_[4], as_[5], bs_[5])]
+                wsb = lib.mm_matmul_workspace_bytes(m_, nn_, *sp, 1, 4)
+                wst = mixedgemm.split_workspace(dev, wsb) if wsb else None
+                fs = lambda: lib.mm_matmul_ws(*pa, m_, nn_, *sp, 1, 4 if wst is not None else 0, None, os_.data_ptr(),
+                                              wst.data_ptr() if wst is not None else None, wst.numel() if wst is not None else 0, stream_ptr)
+                assert fs() == 0
+                settle(fs, 0.15)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(200):
+                    fs()
+                torch.cuda.synchronize()
+                t_s = (time.perf_counter() - t0) / 200
+                wb_ = nn_ * kk_ // 2 + nn_ * kk_ // 32
+                sm[f"{name}_M{m_}"] = {"M": m_, "N": nn_, "K": kk_, "split": list(sp), "us_per_launch": round(t_s * 1e6, 2),
+                                      "weight_stream_TBps": round(wb_ / t_s / 1e12, 3),
+                                      "kernel": lib.mm_matmul_describe(m_, nn_, *sp, 1, 4 if wsb else 0, wsb).decode()[:90]}
+            del bs_
+        sm["note"] = "back-to-back direct C-ABI launches (mm_matmul_ws with the stream's split-K workspace where the plan wants one)"
+        result["small_m"] = sm
         del bf
         result["few_tiles"] = few
 

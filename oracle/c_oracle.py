@@ -36,6 +36,7 @@ def lib():
         _lib.mxo_sf_offset.argtypes = [ctypes.c_int64] * 3
         _lib.mxo_reorder_quantize.restype = ctypes.c_int
         _lib.mxo_matmul.restype = ctypes.c_int
+        _lib.mxo_direct_quantize.restype = ctypes.c_int
     return _lib
 
 
@@ -69,3 +70,18 @@ def matmul(an, bn, a_s, bs, ao, bo, sfan, sfbn, sfas, sfbs, sfao, sfbo):
     if rc:
         raise RuntimeError("mxo_matmul failed")
     return d
+
+
+def direct_quantize(a_bits, b_bits, kn, ks, ko, mode, sf_fill=0):
+    """mode 0: silu(a) * b (activate_quantize_x); 1: a, mixed formats (downproj_quantize_w); 2: a, all fp4 (downproj_quantize_w4)"""
+    from . import mx_oracle as o
+    a_bits = np.ascontiguousarray(a_bits, dtype=np.uint16)
+    b_bits = np.ascontiguousarray(b_bits if b_bits is not None else a_bits, dtype=np.uint16)
+    rows, k = a_bits.shape
+    fm = ("fp4", "fp4", "fp4") if mode == 2 else ("fp4", "fp6", "fp8")
+    outs = [np.zeros((rows, o.packed_width(f, kk)), np.uint8) for f, kk in zip(fm, (kn, ks, ko))]
+    sfs = [np.full((o.sf_size_x(rows, kk),), sf_fill, np.uint8) for kk in (kn, ks, ko)]
+    rc = lib().mxo_direct_quantize(_p(a_bits), _p(b_bits), rows, kn, ks, ko, mode, *[_p(x) for x in outs], *[_p(x) for x in sfs])
+    if rc:
+        raise ValueError("bad split")
+    return (*outs, *sfs)

@@ -21,6 +21,9 @@
  *   mgemm/src/gemm.cu:26-78         three-segment dispatcher (beta = 0,1,1)
  *   mgemm/src/w4a4.cu:27,176        fp32 accumulator, alpha=1 beta=0
  *   mgemm/src/w4a6.cu:178           alpha=1 beta=1
+ *   mgemm/src/activate.cu:29,101    silu(x) = x / (1 + expf(-x)); v = silu(float(a)) * float(b)
+ *   mgemm/src/activate.cu:104-160   per 32 values: amax, scale = amax > 1e-6 ? 2^ceil(log2(amax/FMAX)) : 1, q = RNE(clamp(v/scale))
+ *   mgemm/src/activate.cu:208-500   the same on float(w) for the down_proj weights (mixed and all-fp4)
  *
  * Build: see oracle/Makefile (gcc -O2 -fopenmp -shared -fPIC).
  */
@@ -259,6 +262,68 @@ int mxo_matmul(const uint8_t *AN, const uint8_t *BN, const uint8_t *AS, const ui
         beta = 1;
         free(a);
         free(b);
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Reorder-free ("direct") quantizers, activate.cu -- literal float formulas (expf, ceilf(log2f(.))), natural column order.
+ * mode 0: v = silu(a) * b -> fp4 | fp6 | fp8;  mode 1: v = float(a) -> fp4 | fp6 | fp8;  mode 2: v = float(a) -> fp4 | fp4 | fp4.
+ * Unlike the reorder kernels there is NO bf16 rounding of the scaled value (one rounding from fp32), and an empty block
+ * (amax <= 1e-6) takes scale 1.0 (byte 127).
+ * ------------------------------------------------------------------------------------------------------------ */
+static void pack_codes(const uint8_t *codes, int fmt, uint8_t *out) {
+    if (fmt == FMT_FP8) {
+        memcpy(out, codes, 32);
+    } else if (fmt == FMT_FP6) {
+        for (int i = 0; i < 32; i += 4) {
+            uint8_t a = codes[i] & 0x3F, b = codes[i + 1] & 0x3F, c = codes[i + 2] & 0x3F, d = codes[i + 3] & 0x3F;
+            uint8_t *o = out + (i / 4) * 3;
+            o[0] = (uint8_t)(a | ((b & 0x03) << 6));
+            o[1] = (uint8_t)((b >> 2) | ((c & 0x0F) << 4));
+            o[2] = (uint8_t)((c >> 4) | (d << 2));
+        }
+    } else {
+        for (int i = 0; i < 32; i += 2) out[i / 2] = (uint8_t)((codes[i] & 0xF) | ((codes[i + 1] & 0xF) << 4));
+    }
+}
+
+int mxo_direct_quantize(const uint16_t *a, const uint16_t *b, int rows, int KN, int KS, int KO, int mode, uint8_t *oN, uint8_t *oS,
+                        uint8_t *oO, uint8_t *sfN, uint8_t *sfS, uint8_t *sfO) {
+    const int K = KN + KS + KO;
+    if (KN < 0 || KS < 0 || KO < 0 || K <= 0 || (KN % 128) || (KS % 128) || (KO % 128) || mode < 0 || mode > 2) return 1;
+    const int fN = FMT_FP4, fS = mode == 2 ? FMT_FP4 : FMT_FP6, fO = mode == 2 ? FMT_FP4 : FMT_FP8;
+#pragma omp parallel for schedule(static)
+    for (int r = 0; r < rows; ++r) {
+        for (int g = 0; g < K / 32; ++g) {
+            int fmt, j, kseg;
+            uint8_t *out, *sf;
+            if (g < KN / 32) { fmt = fN; j = g; kseg = KN; out = oN + (int64_t)r * (KN / 32) * group_bytes(fN); sf = sfN; }
+            else if (g < (KN + KS) / 32) { fmt = fS; j = g - KN / 32; kseg = KS; out = oS + (int64_t)r * (KS / 32) * group_bytes(fS); sf = sfS; }
+            else { fmt = fO; j = g - (KN + KS) / 32; kseg = KO; out = oO + (int64_t)r * (KO / 32) * group_bytes(fO); sf = sfO; }
+            float v[32], amax = 0.0f;
+            for (int i = 0; i < 32; ++i) {
+                const float x = bf16_to_f32(a[(int64_t)r * K + g * 32 + i]);
+                v[i] = mode == 0 ? (x / (1.0f + expf(-x))) * bf16_to_f32(b[(int64_t)r * K + g * 32 + i]) : x;
+                const float m = fabsf(v[i]);
+                amax = m > amax ? m : amax;
+            }
+            int e = 0;                                           /* scale 1.0 */
+            if (amax > 1e-6f) {
+                e = (int)ceilf(log2f(amax / FMAXV[fmt]));
+                if (e < -127) e = -127;
+                if (e > 127) e = 127;
+            }
+            const int ec = e < -126 ? -126 : e;                  /* the divisor is a normal fp32 */
+            uint8_t codes[32];
+            for (int i = 0; i < 32; ++i) {
+                float q = (float)((double)v[i] * ldexp(1.0, -ec));
+                q = q < -FMAXV[fmt] ? -FMAXV[fmt] : (q > FMAXV[fmt] ? FMAXV[fmt] : q);
+                codes[i] = (uint8_t)mxo_encode_fast(q, fmt);
+            }
+            pack_codes(codes, fmt, out + (int64_t)j * group_bytes(fmt));
+            sf[sf_offset(r, j, kseg)] = (uint8_t)(e + 127);
+        }
     }
     return 0;
 }

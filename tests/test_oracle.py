@@ -236,6 +236,31 @@ def test_direct_quantizers():
     assert e.tolist() == [0, 1, 0, 7, -1]
 
 
+def test_direct_quantizers_c_restatement_agrees():
+    """oracle/mx_oracle.c follows activate.cu's float formulas literally (expf, ceilf(log2f(amax / FMAX))); the numpy oracle uses the
+    exact exponent and numpy's exp.  Weights (no exp): byte for byte.  silu(a) * b: the two exp implementations may differ in the
+    last ulp, which can move a value across a rounding boundary -- same budget as the GPU test (< 1e-3 of the bytes)."""
+    from oracle import c_oracle
+    rows, k, split = 40, 1024, (512, 256, 256)
+    w = lcg.bf16_normalish(91, (rows, k), exp_spread=6)
+    w[3, 64:96] = 0
+    for mode, w4 in ((1, False), (2, True)):
+        c = c_oracle.direct_quantize(w, None, *split, mode)
+        n = o.downproj_quantize(w, *split, w4=w4)
+        for i in range(3):
+            assert np.array_equal(c[i], n[i]), (mode, i)
+            offs = o.sf_valid_offsets(rows, split[i])
+            assert np.array_equal(c[3 + i][offs], n[3 + i][offs]), (mode, i)
+    a = lcg.bf16_normalish(92, (rows, k), exp_center=128, exp_spread=3)
+    b = lcg.bf16_normalish(93, (rows, k), exp_spread=4)
+    c = c_oracle.direct_quantize(a, b, *split, 0)
+    n = o.activate_quantize(a, b, *split)
+    for i in range(3):
+        assert (c[i] != n[i]).mean() < 1e-3, i
+        offs = o.sf_valid_offsets(rows, split[i])
+        assert (c[3 + i][offs] != n[3 + i][offs]).mean() < 1e-3, i
+
+
 def test_rmsnorm_quantize_oracle_properties():
     """rmsnorm.cu:95-312 restatement: rvar close to the fp64 value; integer_round=False equals reorder_quantize of the
     normalised row; integer_round=True only ever produces integer-valued elements."""

@@ -41,8 +41,8 @@ if plain:
     lines.append(f"== bench.py JSON line of an unprofiled run of the same command on the same box ({CMD}) ==")
     lines.append(plain[-1].strip())
 traffic = None
-SMALL = ("few", "kv", "decode")     # launches that do not fill the chip with 256 eight-wave workgroups
-for name in ("fp8", "fp4", "mixed", "mixed3072", "down") + SMALL:
+SMALL = ("few", "kv", "decode", "gateup")     # launches that are not ONE round of 256 eight-wave workgroups: ratios only
+for name in ("fp8", "fp4", "mixed", "mixed3072", "down") + SMALL:   # (gateup: 1792 workgroups of the fused gate / up kernel)
     d = os.path.join(root, "gpurun_out", f"pmc_{tag}_{name}")
     agg = collections.defaultdict(list)
     for f in glob.glob(d + "/*/*/*_counter_collection.csv"):
@@ -52,7 +52,7 @@ for name in ("fp8", "fp4", "mixed", "mixed3072", "down") + SMALL:
         continue
     head = open(os.path.join(d, "summary.txt")).readline().strip() if os.path.exists(os.path.join(d, "summary.txt")) else name
     lines.append(f"== rocprofv3 --pmc passes -- python3 tools/pmc_target.py ({head}; 10 x quantize_x + matmul" +
-                 (", 4096^3) ==" if name not in SMALL else "; M <= 8: + 10 x the fused decode kernel) =="))
+                 (", 4096^3) ==" if name not in SMALL else "; 10 x quantize_x + mm_gate_up_activate) ==" if name == "gateup" else "; M <= 8: + 10 x the fused decode kernel) =="))
     stat = {}
     for (k, c), v in sorted(agg.items()):
         if "gemm" in k or "reorder" in k or "decode" in k:
