@@ -207,7 +207,7 @@ int mm_matmul_ws(const uint8_t *AN, const uint8_t *BN, const uint8_t *AS, const 
 
 // A kernel, not hipMemsetAsync: captured into a hipGraph (ROCm 7.2, MI355X) a memset node in front of the GEMM gave the right result
 // on the first replay only (later replays were wrong as if the clearing were no longer ordered before the kernel); a kernel node
-// replays in order (tools/_probe_capture.py, profiles/notes_r04.md).
+// replays in order (tools/probe_capture.py, profiles/notes_r04.md).
 static __global__ void ws_reset_kernel(uint4 *p) { p[threadIdx.x] = make_uint4(0u, 0u, 0u, 0u); }
 
 size_t mm_gate_up_activate_workspace_bytes(int M, int I) {
