@@ -261,9 +261,14 @@ def llama_layer(dev, lib, mixedgemm, x, steps):
         fused_dec = m <= 64 and bool(mixedgemm.qlinear_decode_supported(m, H + 2 * NKV, *in_split))
         ent = {"launches_per_layer": 7 if m > 64 else (6 if fused_dec else 8),
                "us_per_layer_stream": round(ts * 1e6, 1), "us_per_layer_graph": round(tg * 1e6, 1) if tg else None,
-               "tokens_per_s_stream": round(m / ts, 1), "tokens_per_s": round(m / (tg or ts), 1),
-               "tokens_per_s_mode": "one hipGraph of the layer's launches" if tg else "stream launches",
-               "tflops": round(flop_per_row * m / (tg or ts) / 1e12, 2)}
+               "tokens_per_s_stream": round(m / ts, 1), "tokens_per_s_graph": round(m / tg, 1) if tg else None}
+        # `tokens_per_s` by a FIXED rule, not the better of the two: prefill-sized batches (M > 64) are GPU-bound and run as stream
+        # launches; decode-sized batches are host-bound from Python and are deployed as one hipGraph of the layer's launches
+        use_graph = m <= 64 and tg is not None
+        t_rule = tg if use_graph else ts
+        ent.update({"tokens_per_s": round(m / t_rule, 1),
+                    "tokens_per_s_mode": "one hipGraph of the layer's launches (M <= 64)" if use_graph else "stream launches (M > 64)",
+                    "tflops": round(flop_per_row * m / t_rule / 1e12, 2)})
         out["by_rows"][str(m)] = ent
     # the MLP at M = 4096 both ways (events around 10 back-to-back repetitions; quantize_x excluded: it is the same launch in both)
     xm = x[:4096].contiguous()
