@@ -25,3 +25,4 @@ def test_cpp_client_of_the_c_abi(dev, m):
     res = subprocess.run([os.path.join(ex, "cabi_demo"), str(m)], capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stdout + res.stderr
     assert "run-to-run differences 0, scale-linearity violations 0" in res.stdout
+    assert "bytes differing from mm_matmul x 2 + mm_activate_quantize: 0" in res.stdout
