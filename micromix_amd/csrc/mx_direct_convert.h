@@ -83,8 +83,12 @@ __device__ __forceinline__ uint32_t quantize32(const float (&v)[32], uint8_t *__
 // total, like the reference's CUDA expf, whose bits are not reproducible on other hardware either).  The full-precision expf +
 // IEEE divide made activate_quantize_x ALU bound at 2.4 TB/s.
 __device__ __forceinline__ float silu_mul(float x, float b) {
+#ifdef MM_ACT_NOSILU      // ablation (results wrong): what the transcendentals cost in the fused epilogue
+    return x * b;
+#else
     const float ex = __builtin_amdgcn_exp2f(x * -1.4426950408889634f);
     return (x * __builtin_amdgcn_rcpf(1.0f + ex)) * b;
+#endif
 }
 
 // eight bf16 (one 16-byte chunk) -> fp32
