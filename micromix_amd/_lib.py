@@ -23,7 +23,7 @@ EXPORTS = (
 )
 # every symbol include/micromix_diag.h declares (libmicromix_diag.so: hardware probes for tests/tools, never used by the ops)
 DIAG_LIB_PATH = os.environ.get("MICROMIX_DIAG_LIB") or os.path.join(_PKG, "lib", "libmicromix_diag.so")
-DIAG_EXPORTS = ("mm_diag_mfma", "mm_diag_hw_convert", "mm_diag_mfma_rate", "mm_diag_l2_bw")
+DIAG_EXPORTS = ("mm_diag_mfma", "mm_diag_hw_convert", "mm_diag_mfma_rate", "mm_diag_l2_bw", "mm_diag_stream_once")
 
 MM_OK, MM_ERR_BAD_SPLIT, MM_ERR_BAD_ARG, MM_ERR_LAUNCH, MM_ERR_UNSUPPORTED, MM_ERR_NO_DEVICE = range(6)
 MM_QUANT_MIXED, MM_QUANT_W4 = 0, 1
@@ -138,6 +138,8 @@ def load_diag():
     lib.mm_diag_mfma_rate.argtypes = [i, i, i, i, i, vp, vp, vp]
     lib.mm_diag_l2_bw.restype = i
     lib.mm_diag_l2_bw.argtypes = [vp, ctypes.c_uint, i, i, i, i, i, vp, vp]
+    lib.mm_diag_stream_once.restype = i
+    lib.mm_diag_stream_once.argtypes = [vp, i, i, i, vp, vp]
     _diag = lib
     return lib
 

@@ -282,6 +282,36 @@ __global__ void __launch_bounds__(256) diag_l2_bw(const uint8_t *buf, unsigned r
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (acc == 12345.678f) sink[0] = acc + smem[tid];
 }
+
+// One pass over `rows` weight rows of `pitch` bytes, 32 rows per 512-thread workgroup, every load of a wave issued before the
+// first use (tools/stream_floor.py: what a launch that only streams the weights of a skinny GEMM costs, by access pattern).
+//   pattern 0: coalesced -- the workgroup's 32 * pitch bytes as one range, a wave-instruction = 1 KiB contiguous
+//   pattern 1: the weight-streaming kernel's -- lane (li, kb) reads 16 B of row li; 64-byte slab s of a row goes to wave s % 8
+//   pattern 2: as 1, but a wave takes both 64-byte halves of a 128-byte line (slabs 2w, 2w + 1, 2w + 16, 2w + 17, ...)
+template <int NL>
+__global__ void __launch_bounds__(512) diag_stream_once(const uint8_t *buf, int pitch, int pattern, float *sink) {
+    typedef int v4i_t __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int li = lane & 31, kb = lane >> 5;
+    const uint8_t *base = buf + (size_t)blockIdx.x * 32 * pitch;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, 32 * pitch, 0x00020000);
+    v4i_t q[NL];
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+        int off;
+        if (pattern == 0) off = (j * 8 + wave) * 1024 + lane * 16;
+        else {
+            const int pair = j >> 1, h = j & 1;                       // two loads per 64-byte slab
+            const int slab = pattern == 1 ? wave + 8 * pair : 2 * wave + (pair & 1) + 16 * (pair >> 1);
+            off = li * pitch + slab * 64 + (2 * h + kb) * 16;
+        }
+        q[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+    }
+    int acc = 0;
+#pragma unroll
+    for (int j = 0; j < NL; ++j) acc ^= q[j][0] ^ q[j][1] ^ q[j][2] ^ q[j][3];
+    if (acc == 0x12345678) sink[0] = 1.0f;
+}
 }  // namespace mm
 
 extern "C" int mm_diag_l2_bw(const void *buf, unsigned region, int stride, int kb_per_iter, int iters, int mode, int blocks,
@@ -295,5 +325,15 @@ extern "C" int mm_diag_l2_bw(const void *buf, unsigned region, int stride, int k
     }
     hipLaunchKernelGGL(mm::diag_l2_bw, dim3(blocks), dim3(256), mode >= 4 ? 49152 : 131072, (hipStream_t)stream, (const uint8_t *)buf, region, stride,
                        kb_per_iter, iters, mode, (float *)sink);
+    return hipGetLastError() == hipSuccess ? MM_OK : MM_ERR_LAUNCH;
+}
+
+// rows % 32 == 0; pitch = bytes per row (1024, 2048 or 4096: every wave issues pitch / 256 loads of 16 B per lane, all before the first use)
+extern "C" int mm_diag_stream_once(const void *buf, int rows, int pitch, int pattern, void *sink, mm_stream_t stream) {
+    if (rows % 32 || (pitch != 1024 && pitch != 2048 && pitch != 4096)) return MM_ERR_BAD_ARG;
+    const dim3 grid(rows / 32), block(512);
+    if (pitch == 1024) hipLaunchKernelGGL(mm::diag_stream_once<4>, grid, block, 0, (hipStream_t)stream, (const uint8_t *)buf, pitch, pattern, (float *)sink);
+    else if (pitch == 2048) hipLaunchKernelGGL(mm::diag_stream_once<8>, grid, block, 0, (hipStream_t)stream, (const uint8_t *)buf, pitch, pattern, (float *)sink);
+    else hipLaunchKernelGGL(mm::diag_stream_once<16>, grid, block, 0, (hipStream_t)stream, (const uint8_t *)buf, pitch, pattern, (float *)sink);
     return hipGetLastError() == hipSuccess ? MM_OK : MM_ERR_LAUNCH;
 }

@@ -38,7 +38,7 @@ hipError_t launch_mx_gemm(const GemmArgs &a, bool w4, hipStream_t stream) {
     if (a.M == 0 || a.N == 0) return hipSuccess;
     static const int skinny_max = getenv("MICROMIX_SKINNY_MAX_M") ? atoi(getenv("MICROMIX_SKINNY_MAX_M")) : 64;   // kernel-developer override (<= 64)
     if (a.M <= skinny_max && !mx_gemm_small_m_uses_tiles(a.M, a.N, a.K, w4, a.ws ? a.ws_bytes : 0, a.force_split != 0))
-        return launch_mx_gemm_skinny(a, w4, stream);
+        return mx_gemm_stream_supported(a.M, a.N, a.K, w4) ? launch_mx_gemm_stream(a, w4, stream) : launch_mx_gemm_skinny(a, w4, stream);
     return launch_mx_gemm256(a, w4, stream);
 }
 

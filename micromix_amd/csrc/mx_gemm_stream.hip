@@ -1,0 +1,407 @@
+// Weight-streaming three-segment MX GEMM for M <= 32 on gfx950, second generation (round 4): the decode / small-batch path of
+// mm_matmul.  Same arithmetic and reference citations as mx_gemm_skinny.hip (gemm.cu:26-78: D = bf16(N); D = bf16(S + D);
+// D = bf16(O + D), fp32 accumulation inside a segment).
+//
+// Why a second kernel.  A launch that ONLY streams the 29 MB of gate_proj's packed weights takes 3.7 us with lane-contiguous loads
+// and 4.9 us with the first kernel's pattern (lane = weight row: 64 separate 16-byte requests per instruction; tools/stream_floor.py;
+// the weights of one layer stay in the Infinity Cache between back-to-back launches).  The first weight-streaming kernel needed
+// 11.6 us at M = 16.  Ablations on a register-ring version of it (profiles/r04_stream_ablation.txt) showed that the time is the sum
+// of its vector-memory instructions, at 30-45 cycles each, whatever they fetch: weights 2.8 us, activations 3.3 us, the three scale
+// dwords per slab 2.7 us -- not a chain of round trips.  A wave instruction whose lanes read consecutive bytes costs bytes / 64
+// cycles instead.  So here EVERY load is lane-contiguous and the MFMA's (lane = row) operand layout is made in LDS:
+//  * one workgroup = 16 * F output features x all tokens, its 8 waves split K: the 128-deep slabs of N | S | O are numbered
+//    through (j = 0 .. T-1) and slab j goes to wave j % 8, whatever segment it belongs to;
+//  * a slab's operand tile (16 rows x C 16-byte chunks per row; C = 4 / 6 / 8 for fp4 / fp6 / fp8) is loaded as chunk e = 64 k + lane
+//    of the tile, row e / C, by instruction k: 4 / 6 / 8 consecutive lanes cover a row's contiguous bytes.  The scale bytes of the
+//    slab's 32 rows are one 8-byte load per lane over the 512-byte atom, handed to the lanes that need them by ds_bpermute;
+//  * the tiles go global -> LDS directly (buffer_load_dwordx4 ... lds, inline asm: no staging registers, no ds_write), into the
+//    wave's PRIVATE ring of D slots; every wave keeps D slabs in flight, issued and consumed in slab order in whole rounds of D
+//    steps with the same number of vector-memory instructions per step, so a counted s_waitcnt vmcnt((D - 1) * L) before a step
+//    leaves exactly the D - 1 younger slabs outstanding (a wave with cnt slabs starts with (D - cnt % D) % D phantom steps that
+//    re-request its first slab and skip the arithmetic).  No barrier: LDS-DMA completion is what vmcnt counts;
+//  * instruction count is the currency: a wave64 VALU instruction holds its SIMD for 4 cycles, a 5 us launch leaves a wave a few
+//    hundred of them.  Everything that depends only on (segment, lane) -- descriptors, byte offsets, LDS addresses -- is computed
+//    once; a step selects by segment with three typed code paths (wave-uniform branches with the same loads in each, so the wait
+//    counts stay exact); workgroups have NW = 4 waves walking 8 slabs each at K = 4096 rather than 8 walking 4;
+//  * a DMA instruction writes its 64 x 16 bytes to LDS in lane order, so WHICH chunk a lane fetches decides the LDS image: lane
+//    p = C' q + c' of a piece fetches chunk c' ^ s(row) of row q (s = row >> 2 for 4 chunks per row, (row >> 1) & 7 for 8): four /
+//    eight consecutive lanes still cover one row's contiguous bytes, and the 16 lanes of a ds_read_b128 phase (16 rows, same chunk)
+//    hit 16 different bank groups.  Consuming a slab = reading the MFMA fragments (lane (row l & 15, K block l >> 4)) and
+//    v_mfma_scale_f32_16x16x128_f8f6f4 with the tokens on the rows; the fragment reads and the MFMA (operand formats are
+//    immediates) sit in a three-way wave-uniform branch; each segment has its own accumulators (a 16 x 16 fp32 tile is 4 registers);
+//  * ONE barrier: every wave leaves its partial sums of all segments in LDS, then thread o sums the eight partials of output o
+//    segment by segment and applies the reference's rounding chain on the reduced values.
+#include <stdlib.h>
+
+#include <type_traits>
+#include <utility>
+
+#include "mx_common.h"
+#include "mx_kernels.h"
+
+namespace mm {
+namespace stream {
+
+// hipcc parses __device__ bodies in its host pass as well; gfx950 inline asm only exists in the device pass
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MM_DEVICE_ONLY(...) __VA_ARGS__
+#else
+#define MM_DEVICE_ONLY(...)
+#endif
+
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v2i __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef int rsrc_t __attribute__((ext_vector_type(4)));
+
+// kernel-developer ablations (tools/build_one_variant.sh): 1 no activation loads, 2 no scale loads, 4 no MFMAs, 8 no reduction / store,
+// 16 no weight loads
+#ifndef MM_STREAM_DBG
+#define MM_STREAM_DBG 0
+#endif
+
+
+// 128-bit raw buffer descriptor {base_lo, base_hi(16 bits) | stride 0, num_records (bytes), flags}, every word provably
+// wave-uniform so that it can be bound to an "s" operand
+__device__ __forceinline__ rsrc_t make_rsrc(const uint8_t *base, unsigned bytes) {
+    const unsigned long long v = (unsigned long long)base;
+    rsrc_t r;
+    r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)v);
+    r[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(v >> 32) & 0xFFFFu));
+    r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+    r[3] = 0x00020000;
+    return r;
+}
+// LDS byte address of a pointer into the workgroup's LDS (the low half of the flat address; see mx_gemm_tile.inc)
+__device__ __forceinline__ unsigned lds_address(const uint8_t *p) { return (unsigned)(unsigned long long)p; }
+
+// one buffer_load_dwordx4 ... lds: 64 lanes x 16 B -> LDS bytes [lds, lds + 1024) in lane order; per-lane source = base + voff + soff
+// (s_nop 4: SALU results may not be read by a VMEM instruction for 5 states; s_nop 0: one state between the M0 write and the DMA)
+__device__ __forceinline__ void dma16(const rsrc_t &rsrc, int voff, int soff, unsigned lds) {
+    MM_DEVICE_ONLY(unsigned keep;
+                   asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                                "buffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
+                                : "=&s"(keep)
+                                : "v"(voff), "s"(rsrc), "s"(lds), "s"(soff)
+                                : "memory");)
+}
+// 8 bytes per lane into registers, NOT tracked by the compiler (the counted waits below order it).  Lane-contiguous on purpose:
+// the same 512 bytes as one dword per lane at a stride of 8 bytes cost the launch 1.5-2.3 us (profiles/r04_stream_ablation.txt).
+__device__ __forceinline__ v2i load_atom(const rsrc_t &rsrc, int voff, int soff) {
+    v2i d = {0, 0};
+    MM_DEVICE_ONLY(asm volatile("s_nop 4\n\tbuffer_load_dwordx2 %0, %1, %2, %3 offen" : "=&v"(d) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");)
+    return d;
+}
+
+// a slab's two 512-byte scale atoms, 8 bytes per lane: lane l holds, of atom row l >> 1, the row groups 2 (l & 1) and 2 (l & 1) + 1
+// (four block scales each)
+struct Slot { v2i sw, sx; };
+
+template <int N>
+__device__ __forceinline__ void wait_slot(Slot &q) {     // at most N vector-memory instructions outstanding; q's registers are valid after it
+    MM_DEVICE_ONLY(asm volatile("s_waitcnt vmcnt(%2)" : "+v"(q.sw), "+v"(q.sx) : "n"(N) : "memory");)
+}
+
+typedef int v6i __attribute__((ext_vector_type(6)));
+template <int EL> struct Frag;                                    // the registers a lane holds of a 128-deep operand row
+template <> struct Frag<0> { typedef v4i type; static constexpr int HW = HW_FP4; };
+template <> struct Frag<1> { typedef v6i type; static constexpr int HW = HW_BF6; };
+template <> struct Frag<2> { typedef v8i type; static constexpr int HW = HW_FP8; };
+
+// The accumulators live in a[0 : 12 F T16 - 1], outside the compiler's register allocation (as in mx_gemm256.hip): tile i of segment
+// g is a[4 (g F T16 + i) .. + 3].  Through the builtin -- or through asm on compiler-owned registers -- hipcc copied the three
+// accumulator sets at the joins of the segment branch (8-16 moves per step).  s_nop 1: two wait states between a just-written
+// source VGPR (the scale shift) and the MFMA -- hipcc pads nothing in front of an asm statement.  Scale bytes: byte 0 of sx / sw.
+#define MM_STREAM_ACC "a0","a1","a2","a3","a4","a5","a6","a7","a8","a9","a10","a11","a12","a13","a14","a15","a16","a17","a18","a19","a20","a21","a22","a23", \
+                      "a24","a25","a26","a27","a28","a29","a30","a31","a32","a33","a34","a35","a36","a37","a38","a39","a40","a41","a42","a43","a44","a45","a46","a47"
+template <int XEL, int WEL, int TILE>
+__device__ __forceinline__ void mfma16(const typename Frag<XEL>::type &x, const typename Frag<WEL>::type &w, int sx, int sw) {
+    static_assert(TILE < 12, "a[0:47]");
+    MM_DEVICE_ONLY(asm volatile("s_nop 1\n\tv_mfma_scale_f32_16x16x128_f8f6f4 a[%c6:%c7], %0, %1, a[%c6:%c7], %2, %3 op_sel_hi:[0,0,0] cbsz:%c4 blgp:%c5"
+                                :
+                                : "v"(x), "v"(w), "v"(sx), "v"(sw), "i"(Frag<XEL>::HW), "i"(Frag<WEL>::HW), "i"(4 * TILE), "i"(4 * TILE + 3)
+                                : MM_STREAM_ACC);)
+}
+template <int REG>
+__device__ __forceinline__ void acc_zero() { MM_DEVICE_ONLY(asm volatile("v_accvgpr_write_b32 a[%c0], 0" ::"i"(REG) : MM_STREAM_ACC);) }
+template <int REG>
+__device__ __forceinline__ float acc_read() {
+    float r = 0.0f;
+    MM_DEVICE_ONLY(asm volatile("v_accvgpr_read_b32 %0, a[%c1]" : "=v"(r) : "i"(REG));)
+    return r;
+}
+template <int N, class Fn>
+__device__ __forceinline__ void static_for(Fn &&fn) {
+    [&]<int... I>(std::integer_sequence<int, I...>) { (fn(std::integral_constant<int, I>{}), ...); }(std::make_integer_sequence<int, N>{});
+}
+
+// one slot of a wave's LDS ring: F weight tiles (one 1 KB piece each with fp4 weights, two otherwise), T16 activation tiles of two pieces
+template <int F, int T16, bool W4>
+struct Ring {
+    static constexpr int WP = W4 ? 1 : 2;
+    static constexpr int W_BYTES = F * WP * 1024, X_BYTES = T16 * 2048, SLOT = W_BYTES + X_BYTES;
+    static constexpr int LOADS = ((MM_STREAM_DBG & 16) ? 0 : F * WP) + ((MM_STREAM_DBG & 1) ? 0 : 2 * T16) + ((MM_STREAM_DBG & 2) ? 0 : 2);
+};
+
+// chunks per row of a segment's 128-deep slab: fp4 4, fp6 6, fp8 8 (x 16 bytes)
+__device__ __forceinline__ constexpr int chunks_of(int g) { return g == 0 ? 4 : (g == 1 ? 6 : 8); }
+
+template <int F, int T16, int D, int NW, bool W4>
+__device__ __forceinline__ void stream_body(const GemmArgs &a) {
+    static_assert(T16 <= 2, "token rows 32 .. 63 sit in row group 1 of the activation scale atoms: one more scale dword per slab");
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];  // the waves' rings [NW][D][Ring::SLOT], then the reduction image
+    using RG = Ring<F, T16, W4>;
+    static_assert((D - 1) * RG::LOADS < 64, "vmcnt is a 6-bit counter");
+    constexpr int BN = 16 * F, ACC = F * T16, NT = 64 * NW;
+    const int n0 = blockIdx.x * BN;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int li = lane & 15, h = lane >> 4, sh = 8 * h;
+    const int ns[3] = {a.K[0] >> 7, a.K[1] >> 7, a.K[2] >> 7};
+    const int c1 = ns[0], c2 = ns[0] + ns[1], T = c2 + ns[2];
+    const int wrows = a.N - n0 > BN ? BN : a.N - n0;
+    const unsigned ring = __builtin_amdgcn_readfirstlane(lds_address(smem) + wave * D * RG::SLOT);   // LDS byte address of slot 0
+    const uint8_t *const ringp = smem + wave * D * RG::SLOT;
+
+    // ---- everything that depends on (segment, lane) only ----
+    // piece k of a 16-row tile with C chunks per row: lane p fetches (row, chunk); its 16 bytes land at LDS byte 1024 k + 16 p
+    //   C = 4 (one piece):   row p >> 2,       chunk (p & 3) ^ (row >> 2)
+    //   C = 8 (two pieces):  row 8 k + (p >> 3), chunk (p & 7) ^ ((row >> 1) & 7)
+    //   C = 6 (1.5 pieces):  chunk e = 64 k + p of the tile in row-major order (rows of 96 bytes stay contiguous in LDS), nothing past e = 95
+    constexpr int OOB = 0x7FFFFF00;     // a byte offset past every descriptor's range: the lane fetches nothing (the DMA writes zeros)
+    const int e1 = 64 + lane;
+    const int r4 = lane >> 2, r8 = lane >> 3;
+    const int ra[3] = {r4, lane / 6, r8}, ca[3] = {(lane & 3) ^ (r4 >> 2), lane % 6, (lane & 7) ^ ((r8 >> 1) & 7)};
+    const int rb[3] = {0, e1 / 6, 8 + r8}, cb[3] = {0, e1 % 6, (lane & 7) ^ (((8 + r8) >> 1) & 7)};
+    const bool vb[3] = {false, lane < 32, true};
+    rsrc_t rw[3], rx[3], rsw[3], rsx[3];
+    int wva[3], wvb[3], xva[3], xvb[3], wpitch[3], xpitch[3];               // byte offsets of this lane's chunks in tile 0, slab 0
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+        const int xc = chunks_of(g), wc = W4 ? 4 : xc, gw = W4 ? 0 : g;
+        xpitch[g] = ns[g] * xc * 16;
+        wpitch[g] = ns[g] * wc * 16;
+        // (the workgroup's own rows as the descriptor's range: rows past N read as zeros, offsets stay small)
+        rw[g] = make_rsrc(a.W[g] + (size_t)n0 * (size_t)wpitch[g], (unsigned)wrows * (unsigned)wpitch[g]);
+        rx[g] = make_rsrc(a.X[g], (unsigned)a.M * (unsigned)xpitch[g]);
+        rsw[g] = make_rsrc(a.SFW[g], (unsigned)a.sfw_row_tiles * (unsigned)ns[g] * 512u);
+        rsx[g] = make_rsrc(a.SFX[g], (unsigned)a.sfx_row_tiles * (unsigned)ns[g] * 512u);
+        wva[g] = ra[gw] * wpitch[g] + ca[gw] * 16;
+        wvb[g] = vb[gw] ? rb[gw] * wpitch[g] + cb[gw] * 16 : OOB;
+        xva[g] = ra[g] * xpitch[g] + ca[g] * 16;
+        xvb[g] = vb[g] ? rb[g] * xpitch[g] + cb[g] * 16 : OOB;
+    }
+    // scale atoms: the dword at byte 8 l + 4 p of a slab's 512-byte atom is (atom row l >> 1, row group 2 (l & 1) + p), its four bytes
+    // the scales of the slab's four 32-blocks.  The workgroup's features share one scale tile (n0 >> 7) and one row group.
+    const int rgw = (n0 >> 5) & 3;
+    const int sf_lane = lane * 8;
+    const bool sfw_hi = (rgw & 1) != 0;
+    int sfw_src[F], sfx_src[T16];                                         // ds_bpermute byte index of the lane that loaded (row, row group)
+#pragma unroll
+    for (int f = 0; f < F; ++f) sfw_src[f] = 4 * (2 * ((n0 + 16 * f + li) & 31) + (rgw >> 1));
+#pragma unroll
+    for (int t = 0; t < T16; ++t) sfx_src[t] = 4 * (2 * (16 * t + li));      // token rows < 32: row group 0
+    // fragment reads: lane (row li, K block h) holds 16 B at chunk h (fp4), 24 B at byte 24 h (fp6), chunks h and 4 + h (fp8) of its row
+    const int s8 = (li >> 1) & 7;
+    const int rd4 = (4 * li + (h ^ (li >> 2))) * 16, rd6 = li * 96 + 24 * h;
+    const int rd8a = (li >> 3) * 1024 + (8 * (li & 7) + (h ^ s8)) * 16, rd8b = (li >> 3) * 1024 + (8 * (li & 7) + ((4 + h) ^ s8)) * 16;
+
+    static_assert(12 * ACC <= 48, "a[0:47]");
+    static_for<12 * ACC>([&](auto r_) { acc_zero<decltype(r_)::value>(); });
+
+    // slab s of segment G into slot d: RG::LOADS vector-memory instructions, whatever the segment
+    auto issue_g = [&](Slot &q, int d, auto G_, int s) {
+        constexpr int G = decltype(G_)::value, XC = chunks_of(G), WC = W4 ? 4 : XC;
+        const unsigned base = ring + d * RG::SLOT;
+        // the scale atoms first: they come from L2 and would otherwise queue behind the slab's weight tiles
+        if constexpr (!(MM_STREAM_DBG & 2)) {
+            q.sw = load_atom(rsw[G], sf_lane, (s + (n0 >> 7) * ns[G]) * 512);
+            q.sx = load_atom(rsx[G], sf_lane, s * 512);
+        }
+        if constexpr (!(MM_STREAM_DBG & 16)) {
+#pragma unroll
+            for (int f = 0; f < F; ++f) {
+                dma16(rw[G], wva[G], s * WC * 16 + 16 * f * wpitch[G], base + f * RG::WP * 1024);
+                if constexpr (!W4) dma16(rw[G], wvb[G], s * WC * 16 + 16 * f * wpitch[G], base + f * RG::WP * 1024 + 1024);
+            }
+        }
+        if constexpr (!(MM_STREAM_DBG & 1)) {
+#pragma unroll
+            for (int t = 0; t < T16; ++t) {
+                dma16(rx[G], xva[G], s * XC * 16 + 16 * t * xpitch[G], base + RG::W_BYTES + t * 2048);
+                dma16(rx[G], xvb[G], s * XC * 16 + 16 * t * xpitch[G], base + RG::W_BYTES + t * 2048 + 1024);
+            }
+        }
+
+    };
+    auto frag = [&](const uint8_t *tile, auto EL_) {
+        constexpr int EL = decltype(EL_)::value;
+        if constexpr (EL == 0) {
+            return *reinterpret_cast<const v4i *>(tile + rd4);
+        } else if constexpr (EL == 1) {
+            const v2i p0 = *reinterpret_cast<const v2i *>(tile + rd6), p1 = *reinterpret_cast<const v2i *>(tile + rd6 + 8),
+                      p2 = *reinterpret_cast<const v2i *>(tile + rd6 + 16);
+            return v6i{p0[0], p0[1], p1[0], p1[1], p2[0], p2[1]};
+        } else {
+            const v4i p = *reinterpret_cast<const v4i *>(tile + rd8a), p2 = *reinterpret_cast<const v4i *>(tile + rd8b);
+            return v8i{p[0], p[1], p[2], p[3], p2[0], p2[1], p2[2], p2[3]};
+        }
+    };
+    auto consume_g = [&](const Slot &q, int d, auto G_) {
+        constexpr int G = decltype(G_)::value, GW = W4 ? 0 : G;
+        const uint8_t *base = ringp + d * RG::SLOT;
+        // scales: the dword of (row, row group) from the lane that loaded it, shifted to this lane's K block
+        int sx[T16], sw[F];
+        const int swv = sfw_hi ? q.sw[1] : q.sw[0];
+#pragma unroll
+        for (int f = 0; f < F; ++f) sw[f] = __builtin_amdgcn_ds_bpermute(sfw_src[f], swv) >> sh;
+#pragma unroll
+        for (int t = 0; t < T16; ++t) sx[t] = __builtin_amdgcn_ds_bpermute(sfx_src[t], q.sx[0]) >> sh;
+        typename Frag<G>::type xv[T16];
+        typename Frag<GW>::type wv[F];
+#pragma unroll
+        for (int t = 0; t < T16; ++t) xv[t] = frag(base + RG::W_BYTES + t * 2048, std::integral_constant<int, G>{});
+#pragma unroll
+        for (int f = 0; f < F; ++f) wv[f] = frag(base + f * RG::WP * 1024, std::integral_constant<int, GW>{});
+        static_for<ACC>([&](auto i_) {
+            constexpr int i = decltype(i_)::value, f = i / T16, t = i % T16;
+            if constexpr (!(MM_STREAM_DBG & 4)) mfma16<G, GW, G * ACC + i>(xv[t], wv[f], sx[t], sw[f]);
+            else { MM_DEVICE_ONLY(asm volatile("" ::"v"(xv[t]), "v"(wv[f]), "v"(sx[t]), "v"(sw[f]));) }
+        });
+    };
+    // slab j of the launch (wave-uniform): segment g, slab j - (first slab of g)
+    auto issue = [&](Slot &q, int d, int j) {
+        if (j < c1) issue_g(q, d, std::integral_constant<int, 0>{}, j);
+        else if (j < c2) issue_g(q, d, std::integral_constant<int, 1>{}, j - c1);
+        else issue_g(q, d, std::integral_constant<int, 2>{}, j - c2);
+    };
+    auto consume = [&](const Slot &q, int d, int j) {
+        if (j < c1) consume_g(q, d, std::integral_constant<int, 0>{});
+        else if (j < c2) consume_g(q, d, std::integral_constant<int, 1>{});
+        else consume_g(q, d, std::integral_constant<int, 2>{});
+    };
+
+    // this wave's slabs: j = wave + NW * i, i = 0 .. cnt-1; `shift` phantom steps in front make the step count a multiple of D
+    const int cnt = wave < T ? (T - wave + NW - 1) / NW : 0;
+    if (cnt > 0) {
+        const int rounds = (cnt + D - 1) / D, shift = rounds * D - cnt;
+        auto slab_of = [&](int step) { const int i = step - shift; return wave + NW * (i > 0 ? i : 0); };
+        Slot q[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) q[d].sw = q[d].sx = v2i{0, 0};
+#pragma unroll
+        for (int d = 0; d < D; ++d) issue(q[d], d, slab_of(d));
+        for (int r = 0; r + 1 < rounds; ++r) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const int step = r * D + d;
+                wait_slot<(D - 1) * RG::LOADS>(q[d]);
+                if (step >= shift) consume(q[d], d, slab_of(step));
+                MM_DEVICE_ONLY(asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");)   // the slot's fragments are in registers before it is refilled
+                issue(q[d], d, slab_of(step + D));
+            }
+        }
+        auto last = [&](auto d_) {      // the last round: nothing is requested any more, the younger slabs are the later slots only
+            constexpr int d = decltype(d_)::value;
+            const int step = (rounds - 1) * D + d;
+            wait_slot<(D - 1 - d) * RG::LOADS>(q[d]);
+            if (step >= shift) consume(q[d], d, slab_of(step));
+        };
+        [&]<int... I>(std::integer_sequence<int, I...>) { (last(std::integral_constant<int, I>{}), ...); }(std::make_integer_sequence<int, D>{});
+    }
+
+    MM_DEVICE_ONLY(asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" ::: "memory");)    // the last MFMA's result may be read (18 wait states)
+    if constexpr (MM_STREAM_DBG & 8) {
+        float t = 0.0f;
+        static_for<12 * ACC>([&](auto r_) { t += acc_read<decltype(r_)::value>(); });
+        if (t == 12345.678f) a.D[0] = 1;
+        return;
+    }
+    // ---- cross-wave reduction: partial sums of the present segments side by side, one barrier ----
+    const int p0 = ns[0] ? 1 : 0, p1 = ns[1] ? 1 : 0, p2 = ns[2] ? 1 : 0, P = p0 + p1 + p2;
+    constexpr int IMG = ACC * 4 * 64;                   // floats per wave and segment
+    float *const red = reinterpret_cast<float *>(smem);
+    {
+        __syncthreads();       // every wave is done with its ring: the reduction image reuses it
+        float *mine = red + (size_t)wave * P * IMG;
+        int slot = 0;
+        static_for<3>([&](auto g_) {
+            constexpr int g = decltype(g_)::value;
+            const int present = g == 0 ? p0 : (g == 1 ? p1 : p2);
+            if (present) {
+                static_for<4 * ACC>([&](auto r_) {
+                    constexpr int r = decltype(r_)::value;      // register r & 3 of tile r >> 2
+                    mine[slot * IMG + r * 64 + lane] = acc_read<4 * g * ACC + r>();
+                });
+                ++slot;
+            }
+        });
+    }
+    __syncthreads();
+    // output o = (i = f * T16 + t, r, l): token 16 t + 4 (l >> 4) + r, feature n0 + 16 f + (l & 15)
+    constexpr int OUTS = ACC * 256;
+#pragma unroll
+    for (int o = threadIdx.x; o < OUTS; o += NT) {
+        float run = 0.0f;
+        for (int slot = 0; slot < P; ++slot) {
+            float s = 0.0f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) s += red[((size_t)w * P + slot) * IMG + o];
+            s += run;
+            run = a.round_per_segment ? bf16_bits_to_f32(f32_to_bf16_bits(s)) : s;
+        }
+        const int l = o & 63, r = (o >> 6) & 3, i = o >> 8;
+        const int f = i / T16, t = i % T16;
+        const int m = 16 * t + 4 * (l >> 4) + r, n = n0 + 16 * f + (l & 15);
+        if (m < a.M && n < a.N) {
+            if (a.out_f32) {
+                reinterpret_cast<float *>(a.D)[(size_t)m * a.N + n] = run;
+            } else {
+                uint32_t b = f32_to_bf16_bits(run);
+                if (a.bias != nullptr) b = f32_to_bf16_bits(bf16_bits_to_f32(b) + bf16_bits_to_f32(a.bias[n]));
+                a.D[(size_t)m * a.N + n] = (uint16_t)b;
+            }
+        }
+    }
+}
+
+template <int F, int T16, int D, int NW, bool W4>
+__global__ void __launch_bounds__(64 * NW) mx_gemm_stream_kernel(GemmArgs a) { stream_body<F, T16, D, NW, W4>(a); }
+
+template <int F, int T16, int D, int NW, bool W4>
+static hipError_t launch_one(const GemmArgs &a, hipStream_t stream) {
+    const int present = (a.K[0] ? 1 : 0) + (a.K[1] ? 1 : 0) + (a.K[2] ? 1 : 0);
+    const int red_bytes = NW * present * F * T16 * 4 * 64 * (int)sizeof(float), stage_bytes = NW * D * Ring<F, T16, W4>::SLOT;
+    const int lds = red_bytes > stage_bytes ? red_bytes : stage_bytes;
+    static DynamicLdsOnce once;
+    if (lds > 65536) {
+        constexpr int MAX_RED = NW * 3 * F * T16 * 1024, MAX_STAGE = NW * D * Ring<F, T16, W4>::SLOT;
+        hipError_t e = once.ensure(reinterpret_cast<const void *>(mx_gemm_stream_kernel<F, T16, D, NW, W4>), MAX_RED > MAX_STAGE ? MAX_RED : MAX_STAGE);
+        if (e != hipSuccess) return e;
+    }
+    const int blocks = (a.N + 16 * F - 1) / (16 * F);
+    MM_LAUNCH((mx_gemm_stream_kernel<F, T16, D, NW, W4>), dim3(blocks), dim3(64 * NW), lds, stream, a);
+    return hipGetLastError();
+}
+
+}  // namespace stream
+
+bool mx_gemm_stream_supported(int M, int N, const int K[3], bool w4) {
+    static const int on = getenv("MICROMIX_STREAM") ? atoi(getenv("MICROMIX_STREAM")) : 1;   // kernel-developer override
+    (void)N; (void)K; (void)w4;
+    return on && M <= 32;
+}
+
+hipError_t launch_mx_gemm_stream(const GemmArgs &a, bool w4, hipStream_t stream) {
+    using namespace stream;
+    const int cus = device_cus();
+    // 32 features per workgroup once those fill the CUs, 16 below (q/o at N = 4096: 256 workgroups instead of 128)
+    const bool wide = (a.N + 31) / 32 >= cus;
+#define MM_STREAM(F_, T_, D_, NW_)                                                   \
+    (w4 ? launch_one<F_, T_, D_, NW_, true>(a, stream) : launch_one<F_, T_, D_, NW_, false>(a, stream))
+    if (a.M <= 16) return wide ? MM_STREAM(2, 1, 4, 4) : MM_STREAM(1, 1, 4, 4);
+    return wide ? MM_STREAM(2, 2, 4, 4) : MM_STREAM(1, 2, 4, 4);
+#undef MM_STREAM
+}
+
+}  // namespace mm

@@ -152,6 +152,9 @@ bool mx_gemm_act_supported(int M, int N);                                 // the
 hipError_t launch_mx_gemm_act(const GemmArgs &a, hipStream_t stream);    // fp4 weights only
 const char *describe_mx_gemm_act(int M, int N);
 hipError_t launch_mx_gemm_skinny(const GemmArgs &a, bool w4, hipStream_t stream);
+// second-generation weight-streaming kernel (mx_gemm_stream.hip): M <= 32
+bool mx_gemm_stream_supported(int M, int N, const int K[3], bool w4);
+hipError_t launch_mx_gemm_stream(const GemmArgs &a, bool w4, hipStream_t stream);
 hipError_t launch_mx_gemm_skinny_grouped(const GroupedGemmArgs &ga, int max_m, bool w4, hipStream_t stream);
 size_t mx_gemm_workspace_bytes(int M, int N, const int K[3], bool w4, bool force, bool tickets_zeroed);
 bool mx_gemm_small_m_uses_tiles(int M, int N, const int K[3], bool w4, size_t ws_bytes, bool force_split);
