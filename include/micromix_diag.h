@@ -31,6 +31,10 @@ int mm_diag_mfma_rate(int shape, int el_a, int el_b, int blocks, int iters, cons
  * mode 0 = register loads, 1 = contiguous LDS-DMA, 2 = LDS-DMA of 8 x 128-byte rows `stride` bytes apart. */
 int mm_diag_l2_bw(const void *buf, unsigned region, int stride, int kb_per_iter, int iters, int mode, int blocks, void *sink,
                   mm_stream_t stream);
+/* One pass over `rows` rows of `pitch` bytes (1024, 2048 or 4096; rows % 32 == 0), 32 rows per 512-thread workgroup, every load issued
+ * before the first use, nothing computed or written: what a launch that only streams a small-M GEMM's weights costs, by access pattern
+ * (0 lane-contiguous, 1 lane = row with 64-byte slab s on wave s % 8, 2 the same with whole 128-byte lines per wave). tools/stream_floor.py */
+int mm_diag_stream_once(const void *buf, int rows, int pitch, int pattern, void *sink, mm_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -262,7 +262,7 @@ const char *mm_test_function(void);
  * The in-kernel clock stamps (mm_diag_set_clock_buffer) and the MM_DBG ablation switches exist only in the instrumented
  * developer variant of the library (-DMM_INSTRUMENT, csrc/mx_instrument.h, tools/build_variant.sh); the default library neither
  * exports that symbol nor contains the stores.  The hardware microbenchmarks and probes (mm_diag_mfma, mm_diag_hw_convert,
- * mm_diag_mfma_rate, mm_diag_l2_bw) live in libmicromix_diag.so, declared in include/micromix_diag.h.
+ * mm_diag_mfma_rate, mm_diag_l2_bw, mm_diag_stream_once) live in libmicromix_diag.so, declared in include/micromix_diag.h.
  */
 int mm_diag_set_kernel_events(void *start_event, void *stop_event);
 #ifdef MM_INSTRUMENT

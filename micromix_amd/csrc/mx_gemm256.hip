@@ -467,6 +467,10 @@ bool mx_gemm_small_m_uses_tiles(int M, int N, const int K[3], bool w4, size_t ws
     // tools/time_skinny_big_n.py, profiles/notes_r03.md section 24)
     // (round 4: with the 32 x 64 tiles also M <= 16 -- N = 28672, us at M = 1 / 8 / 16 / 24 / 32: weight-streaming or 64 x 64 tiles
     // 17.4 / 18.6 / 20.3 / 18.6 / 18.6, 32 x 64 tiles 16.7 / 16.8 / 16.7 / 16.9 / 16.9; at N <= 14336 the weight-streaming kernel wins by 1-4 us)
+    // (round 4, later: the second weight-streaming kernel, mx_gemm_stream.hip, takes 14.3-14.6 us at N = 28672 and M <= 16, 20.2 at
+    // M = 32 where the 32 x 64 tiles take 16.8; MICROMIX_SMALL_M_TILES=1 restores the rule above for A/B runs)
+    static const int tiles_le16 = env_int("MICROMIX_SMALL_M_TILES", 0);
+    if (M <= 16 && !tiles_le16) return false;
     if (M <= 32) return (N + 31) / 32 > 3 * device_cus();
     if (M <= 32 || M > 64) return M > 64;
     if ((N + 31) / 32 > device_cus()) return true;

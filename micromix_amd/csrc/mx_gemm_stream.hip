@@ -31,6 +31,7 @@
 //    immediates) sit in a three-way wave-uniform branch; each segment has its own accumulators (a 16 x 16 fp32 tile is 4 registers);
 //  * ONE barrier: every wave leaves its partial sums of all segments in LDS, then thread o sums the eight partials of output o
 //    segment by segment and applies the reference's rounding chain on the reduced values.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include <type_traits>
@@ -73,11 +74,14 @@ __device__ __forceinline__ rsrc_t make_rsrc(const uint8_t *base, unsigned bytes)
     r[3] = 0x00020000;
     return r;
 }
+
 // LDS byte address of a pointer into the workgroup's LDS (the low half of the flat address; see mx_gemm_tile.inc)
 __device__ __forceinline__ unsigned lds_address(const uint8_t *p) { return (unsigned)(unsigned long long)p; }
 
 // one buffer_load_dwordx4 ... lds: 64 lanes x 16 B -> LDS bytes [lds, lds + 1024) in lane order; per-lane source = base + voff + soff
-// (s_nop 4: SALU results may not be read by a VMEM instruction for 5 states; s_nop 0: one state between the M0 write and the DMA)
+// (s_nop 4: SALU results may not be read by a VMEM instruction for 5 states; s_nop 0: one state between the M0 write and the DMA).
+// (The same tiles through registers -- buffer_load_dwordx4 into a register ring, ds_write_b128 in lane order when a slab is consumed --
+// measured the same times at 118 instead of 53 VGPRs: profiles/r04_stream_ablation.txt, section 6.)
 __device__ __forceinline__ void dma16(const rsrc_t &rsrc, int voff, int soff, unsigned lds) {
     MM_DEVICE_ONLY(unsigned keep;
                    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
@@ -147,10 +151,21 @@ struct Ring {
 // chunks per row of a segment's 128-deep slab: fp4 4, fp6 6, fp8 8 (x 16 bytes)
 __device__ __forceinline__ constexpr int chunks_of(int g) { return g == 0 ? 4 : (g == 1 ? 6 : 8); }
 
+#ifndef MM_STREAM_CLOCK     // kernel-developer build: wave 0 of every workgroup leaves 100 MHz timestamps (start, ring primed, loop done, barrier passed, end)
+#define MM_STREAM_CLOCK 0
+#endif
+#if MM_STREAM_CLOCK
+__device__ unsigned long long *g_stream_clock;
+#define MM_STAMP(i) do { if (threadIdx.x == 0 && g_stream_clock) g_stream_clock[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define MM_STAMP(i) do { } while (0)
+#endif
+
 template <int F, int T16, int D, int NW, bool W4>
 __device__ __forceinline__ void stream_body(const GemmArgs &a) {
     static_assert(T16 <= 2, "token rows 32 .. 63 sit in row group 1 of the activation scale atoms: one more scale dword per slab");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];  // the waves' rings [NW][D][Ring::SLOT], then the reduction image
+    MM_STAMP(0);
     using RG = Ring<F, T16, W4>;
     static_assert((D - 1) * RG::LOADS < 64, "vmcnt is a 6-bit counter");
     constexpr int BN = 16 * F, ACC = F * T16, NT = 64 * NW;
@@ -192,13 +207,16 @@ __device__ __forceinline__ void stream_body(const GemmArgs &a) {
         xvb[g] = vb[g] ? rb[g] * xpitch[g] + cb[g] * 16 : OOB;
     }
     // scale atoms: the dword at byte 8 l + 4 p of a slab's 512-byte atom is (atom row l >> 1, row group 2 (l & 1) + p), its four bytes
-    // the scales of the slab's four 32-blocks.  The workgroup's features share one scale tile (n0 >> 7) and one row group.
-    const int rgw = (n0 >> 5) & 3;
+    // the scales of the slab's four 32-blocks.  The workgroup's features share one scale tile (n0 >> 7).
     const int sf_lane = lane * 8;
-    const bool sfw_hi = (rgw & 1) != 0;
+    bool sfw_hi[F];                                                       // wave-uniform: the feature tile's row group is odd
     int sfw_src[F], sfx_src[T16];                                         // ds_bpermute byte index of the lane that loaded (row, row group)
 #pragma unroll
-    for (int f = 0; f < F; ++f) sfw_src[f] = 4 * (2 * ((n0 + 16 * f + li) & 31) + (rgw >> 1));
+    for (int f = 0; f < F; ++f) {
+        const int rg = ((n0 + 16 * f) >> 5) & 3;
+        sfw_hi[f] = (rg & 1) != 0;
+        sfw_src[f] = 4 * (2 * ((n0 + 16 * f + li) & 31) + (rg >> 1));
+    }
 #pragma unroll
     for (int t = 0; t < T16; ++t) sfx_src[t] = 4 * (2 * (16 * t + li));      // token rows < 32: row group 0
     // fragment reads: lane (row li, K block h) holds 16 B at chunk h (fp4), 24 B at byte 24 h (fp6), chunks h and 4 + h (fp8) of its row
@@ -232,7 +250,6 @@ __device__ __forceinline__ void stream_body(const GemmArgs &a) {
                 dma16(rx[G], xvb[G], s * XC * 16 + 16 * t * xpitch[G], base + RG::W_BYTES + t * 2048 + 1024);
             }
         }
-
     };
     auto frag = [&](const uint8_t *tile, auto EL_) {
         constexpr int EL = decltype(EL_)::value;
@@ -252,9 +269,8 @@ __device__ __forceinline__ void stream_body(const GemmArgs &a) {
         const uint8_t *base = ringp + d * RG::SLOT;
         // scales: the dword of (row, row group) from the lane that loaded it, shifted to this lane's K block
         int sx[T16], sw[F];
-        const int swv = sfw_hi ? q.sw[1] : q.sw[0];
 #pragma unroll
-        for (int f = 0; f < F; ++f) sw[f] = __builtin_amdgcn_ds_bpermute(sfw_src[f], swv) >> sh;
+        for (int f = 0; f < F; ++f) sw[f] = __builtin_amdgcn_ds_bpermute(sfw_src[f], sfw_hi[f] ? q.sw[1] : q.sw[0]) >> sh;
 #pragma unroll
         for (int t = 0; t < T16; ++t) sx[t] = __builtin_amdgcn_ds_bpermute(sfx_src[t], q.sx[0]) >> sh;
         typename Frag<G>::type xv[T16];
@@ -291,6 +307,7 @@ __device__ __forceinline__ void stream_body(const GemmArgs &a) {
         for (int d = 0; d < D; ++d) q[d].sw = q[d].sx = v2i{0, 0};
 #pragma unroll
         for (int d = 0; d < D; ++d) issue(q[d], d, slab_of(d));
+        MM_STAMP(1);
         for (int r = 0; r + 1 < rounds; ++r) {
 #pragma unroll
             for (int d = 0; d < D; ++d) {
@@ -310,6 +327,7 @@ __device__ __forceinline__ void stream_body(const GemmArgs &a) {
         [&]<int... I>(std::integer_sequence<int, I...>) { (last(std::integral_constant<int, I>{}), ...); }(std::make_integer_sequence<int, D>{});
     }
 
+    MM_STAMP(2);
     MM_DEVICE_ONLY(asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" ::: "memory");)    // the last MFMA's result may be read (18 wait states)
     if constexpr (MM_STREAM_DBG & 8) {
         float t = 0.0f;
@@ -338,6 +356,7 @@ __device__ __forceinline__ void stream_body(const GemmArgs &a) {
         });
     }
     __syncthreads();
+    MM_STAMP(3);
     // output o = (i = f * T16 + t, r, l): token 16 t + 4 (l >> 4) + r, feature n0 + 16 f + (l & 15)
     constexpr int OUTS = ACC * 256;
 #pragma unroll
@@ -363,6 +382,7 @@ __device__ __forceinline__ void stream_body(const GemmArgs &a) {
             }
         }
     }
+    MM_STAMP(4);
 }
 
 template <int F, int T16, int D, int NW, bool W4>
@@ -386,11 +406,25 @@ static hipError_t launch_one(const GemmArgs &a, hipStream_t stream) {
 
 }  // namespace stream
 
+#if MM_STREAM_CLOCK
+extern "C" int mm_diag_set_stream_clock(void *buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(stream::g_stream_clock), &buf, sizeof(buf)) == hipSuccess ? 0 : 3;
+}
+#endif
+
 bool mx_gemm_stream_supported(int M, int N, const int K[3], bool w4) {
     static const int on = getenv("MICROMIX_STREAM") ? atoi(getenv("MICROMIX_STREAM")) : 1;   // kernel-developer override
-    (void)N; (void)K; (void)w4;
-    return on && M <= 32;
+    (void)w4;
+    if (!on || M > 32) return false;
+    // few features, short K, a handful of tokens (q/k/v/o at M <= 8): the launch is all start-up, and the first kernel's is shorter
+    // (q/o at M = 1: 4.65 against 5.0-5.5 us; from M = 16 on the two meet)
+    if (M <= 8 && (N + 15) / 16 <= device_cus() && K[0] + K[1] + K[2] <= 8192) return false;
+    return true;
 }
+
+#ifndef MM_STREAM_SWEEP      // kernel-developer build: every (F, D, NW) combination, picked by MICROMIX_STREAM_CFG="F,D,NW"
+#define MM_STREAM_SWEEP 0
+#endif
 
 hipError_t launch_mx_gemm_stream(const GemmArgs &a, bool w4, hipStream_t stream) {
     using namespace stream;
@@ -399,8 +433,25 @@ hipError_t launch_mx_gemm_stream(const GemmArgs &a, bool w4, hipStream_t stream)
     const bool wide = (a.N + 31) / 32 >= cus;
 #define MM_STREAM(F_, T_, D_, NW_)                                                   \
     (w4 ? launch_one<F_, T_, D_, NW_, true>(a, stream) : launch_one<F_, T_, D_, NW_, false>(a, stream))
-    if (a.M <= 16) return wide ? MM_STREAM(2, 1, 4, 4) : MM_STREAM(1, 1, 4, 4);
-    return wide ? MM_STREAM(2, 2, 4, 4) : MM_STREAM(1, 2, 4, 4);
+#if MM_STREAM_SWEEP
+    static int cf = 0, cd = 0, cn = 0;
+    static const bool have = getenv("MICROMIX_STREAM_CFG") && sscanf(getenv("MICROMIX_STREAM_CFG"), "%d,%d,%d", &cf, &cd, &cn) == 3;
+    if (have) {
+#define MM_TRY(F_, D_, NW_)                                                                              \
+    if (cf == F_ && cd == D_ && cn == NW_) return a.M <= 16 ? MM_STREAM(F_, 1, D_, NW_) : MM_STREAM(F_, 2, D_, NW_);
+        if (cf == 4 && cd == 4 && cn == 4 && a.M <= 16) return MM_STREAM(4, 1, 4, 4);
+        if (cf == 4 && cd == 3 && cn == 8 && a.M <= 16) return MM_STREAM(4, 1, 3, 8);
+        if (cf == 4 && cd == 4 && cn == 8 && a.M <= 16) return MM_STREAM(4, 1, 4, 8);
+        MM_TRY(1, 4, 4) MM_TRY(1, 6, 4) MM_TRY(1, 4, 8) MM_TRY(1, 2, 8) MM_TRY(1, 3, 8) MM_TRY(1, 2, 16)
+        MM_TRY(2, 3, 4) MM_TRY(2, 4, 4) MM_TRY(2, 4, 8) MM_TRY(2, 3, 8) MM_TRY(2, 2, 8) MM_TRY(2, 2, 16) MM_TRY(2, 1, 16)
+#undef MM_TRY
+        return hipErrorInvalidValue;
+    }
+#endif
+    // (slots, waves) from sweeps on three boxes (profiles/r04_stream_ablation.txt, section 7): more waves with a shallow ring beat fewer
+    // with a deep one; 32 tokens x 32 features: four waves, so that two workgroups fit a CU's LDS
+    if (a.M <= 16) return wide ? MM_STREAM(2, 1, 2, 8) : MM_STREAM(1, 1, 3, 8);
+    return wide ? MM_STREAM(2, 2, 3, 4) : MM_STREAM(1, 2, 3, 8);
 #undef MM_STREAM
 }
 

@@ -474,6 +474,52 @@ def test_every_tile_kernel(dev, ns, tile, M, N, wmode):
         check_gemm(bits_from_t(d)[rows], qx, [u8(t) for t in b], rounding, label=f"{ns} {M}x{N} {wmode} {rounding}")
 
 
+# The second weight-streaming kernel (mx_gemm_stream.hip, M <= 32): every instantiation -- 16 / 32 features per workgroup x one / two
+# 16-token tiles x both weight modes -- on all rows, with the cases its ring has to get right: fewer slabs than waves (idle waves),
+# slab counts that need 1 .. D - 1 phantom steps, a lone fp6 slab between long segments, absent segments, N that is not a multiple of
+# the workgroup's features, a long K (14 slabs per wave), bias, the fp32 output and the single-rounding mode.
+STREAM_CASES = [
+    # (M, N, split)                          what it exercises
+    (9, 4128, (256, 128, 256)),            # narrow (16 features), 5 slabs < 8 waves
+    (16, 272, (1024, 128, 896)),           # narrow, 16 slabs: two per wave, N = 17 x 16
+    (12, 200, (128, 0, 0)),                # one slab, N % 16 != 0
+    (3, 8200, (2048, 128, 1920)),          # wide (32 features, N / 32 > CUs), 32 slabs, ragged last workgroup (8200 = 256 x 32 + 8)
+    (16, 8448, (0, 0, 1152)),              # wide, fp8 only, 9 slabs: one wave has two
+    (14, 8256, (640, 0, 0)),               # wide, fp4 only
+    (11, 8192, (0, 1280, 0)),              # wide, fp6 only (the 1.5-piece tiles)
+    (1, 1024, (12288, 1024, 1024)),        # down_proj's K: 112 slabs, 14 per wave
+    (17, 528, (384, 128, 640)),            # two token tiles, narrow, 9 slabs
+    (32, 8224, (512, 128, 384)),           # two token tiles, wide, ragged N
+    (25, 4100, (0, 256, 2048)),            # two token tiles, no fp4 segment
+    (32, 300, (3072, 896, 128)),           # two token tiles, 32 slabs
+]
+
+
+@pytest.mark.parametrize("wmode", ("w4", "w"))
+@pytest.mark.parametrize("m,n,split", STREAM_CASES, ids=[f"{c[0]}x{c[1]}-{'_'.join(map(str, c[2]))}" for c in STREAM_CASES])
+def test_weight_streaming_kernel(dev, m, n, split, wmode):
+    import torch
+    from micromix_amd import _lib
+    k = sum(split)
+    desc = _lib.load().mm_matmul_describe(m, n, *split, 1 if wmode == "w4" else 0, 0, 0).decode()
+    assert "mx_gemm_stream_kernel" in desc, desc
+    rng = np.random.default_rng(m * 131 + n)
+    qx, qw = quantized(rng, m, n, k, split, wmode)
+    for rounding in ("reference", "fused"):
+        got = gpu_matmul(dev, qx, qw, rounding=rounding)
+        check_gemm(got, qx, qw, rounding, label=f"stream {m}x{n}x{k} {split} {wmode} {rounding}")
+    # bias: the reference's two roundings (qLinearLayer.py:70-71), as a separate add on the GPU result
+    a, b = to_dev(dev, qx), to_dev(dev, qw)
+    bias = torch.from_numpy(rng.standard_normal(n).astype(np.float32)).to(torch.bfloat16).to(dev)
+    args = (a[0], b[0], a[1], b[1], a[2], b[2], a[3], b[3], a[4], b[4], a[5], b[5])
+    plain = mixedgemm.matmul(*args)
+    with_bias = mixedgemm.matmul(*args, bias=bias)
+    assert torch.equal(with_bias, (plain.float() + bias.float()).to(torch.bfloat16))
+    # fp32 partial sums (tensor-parallel shards): rounding them once gives the single-rounding result
+    f32 = mixedgemm.matmul(*args, rounding="fused", out_dtype=torch.float32)
+    assert torch.equal(f32.to(torch.bfloat16), mixedgemm.matmul(*args, rounding="fused"))
+
+
 # Chained segment hand-over of the 256-row tile (run_slabs_big, fp4 weights): every way a segment can pass its successor's first slabs
 # on -- fp4 ring of 2 / 3 / 6 slabs into S or straight into O, successors shorter than, equal to and longer than their ring, S -> O
 # through one ring, a segment shorter than the ring that owes its successor's slabs, and the cases that must NOT chain (odd fp4

@@ -1,0 +1,38 @@
+"""Where a workgroup of the weight-streaming kernel spends its time: python tools/stream_clock.py [M]  with
+MICROMIX_HIP_LIB=micromix_amd/lib/dbg/lib_sclock.so (tools/build_one_variant.sh sclock mx_gemm_stream -DMM_STREAM_CLOCK=1).
+Wave 0 of every workgroup stamps the 100 MHz clock at: start, ring primed (first D slabs requested), loop done, barrier passed, end."""
+import ctypes, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from micromix_amd import _lib, mixedgemm
+lib = _lib.load(); dev = torch.device("cuda:0")
+lib.mm_diag_set_stream_clock.restype = ctypes.c_int
+lib.mm_diag_set_stream_clock.argtypes = [ctypes.c_void_p]
+g = torch.Generator().manual_seed(0)
+st = torch.cuda.current_stream().cuda_stream
+pp = lambda t: t.data_ptr() if t.numel() else None
+M = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+for name, N, K, split in (("q/o", 4096, 4096, (2048, 128, 1920)), ("gate/up", 14336, 4096, (2048, 128, 1920)), ("down", 4096, 14336, (12288, 1024, 1024))):
+    w = (torch.randn((N, K), generator=g) * 0.02).to(torch.bfloat16).to(dev)
+    idx = torch.randperm(K, generator=g).to(torch.int16).to(dev)
+    b = mixedgemm.reorder_quantize_w4(w, idx, *split)
+    x = torch.randn((M, K), generator=g).to(torch.bfloat16).to(dev)
+    a = mixedgemm.reorder_quantize_x(x, idx, *split)
+    out = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+    ptrs = [pp(t) for t in (a[0], b[0], a[1], b[1], a[2], b[2], a[3], b[3], a[4], b[4], a[5], b[5])]
+    f = lambda: lib.mm_matmul(*ptrs, M, N, *split, 1, 0, None, out.data_ptr(), st)
+    clock = torch.zeros((4096, 8), dtype=torch.int64, device=dev)
+    assert lib.mm_diag_set_stream_clock(clock.data_ptr()) == 0
+    for _ in range(50): f()
+    torch.cuda.synchronize()
+    clock.zero_(); torch.cuda.synchronize()
+    f(); torch.cuda.synchronize()
+    c = clock.cpu().numpy()
+    c = c[c[:, 0] > 0][:, :5].astype(np.float64) / 100.0          # us
+    t0 = c[:, 0].min()
+    ph = np.diff(c, axis=1)
+    print(f"{name:8s} M={M} N={N} K={K}: {len(c)} workgroups; start spread {c[:, 0].max() - t0:.2f} us; last end {c[:, 4].max() - t0:.2f} us after the first start; "
+          f"per workgroup (median / max us): prime {np.median(ph[:, 0]):.2f}/{ph[:, 0].max():.2f}  loop {np.median(ph[:, 1]):.2f}/{ph[:, 1].max():.2f}  "
+          f"barrier {np.median(ph[:, 2]):.2f}/{ph[:, 2].max():.2f}  reduce+store {np.median(ph[:, 3]):.2f}/{ph[:, 3].max():.2f}  total {np.median(c[:, 4] - c[:, 0]):.2f}/{(c[:, 4] - c[:, 0]).max():.2f}", flush=True)
