@@ -1,0 +1,87 @@
+// Phase 1 of the decode-sized QLinearLayer.forward kernels (qlinear_decode.hip, and the QUANT mode of mx_gemm_stream.hip): every
+// workgroup quantizes the M <= 8 activation rows into LDS by itself -- reorder + per-32 absmax + UE8M0 scale + MXFP4/6/8 codes,
+// reorder.cu:94-269 per group, through the shared quantize_group of mx_group_convert.h: the bytes of reorder_quantize_x.
+#pragma once
+#include "mx_group_convert.h"
+
+namespace mm {
+namespace dq {
+
+struct QuantIn {
+    const uint16_t *X;      // [M, K] bf16
+    const int16_t *idx;     // [K]
+    int K[3];
+    int M;
+    int stage_rows;         // activation rows staged in LDS at a time (launcher: as many as fit)
+};
+
+// LDS map: [staged bf16 rows | opN | opS | opO | scale bytes]; row r of a segment at op + r * pitch, its scale bytes at
+// scales + r * Gt + (first group of the segment)
+struct LdsMap {
+    uint8_t *opN, *opS, *opO, *scales;
+    int pN, pS, pO, Gt, gN, gS;
+};
+__host__ __device__ inline size_t operand_bytes(int M, const int K[3]) {   // quantized rows + their scale bytes
+    const size_t Kt = (size_t)K[0] + K[1] + K[2];
+    return (size_t)M * (K[0] / 2 + K[1] / 4 * 3 + K[2] + Kt / 32);
+}
+
+// phase 1: quantize the M activation rows into LDS (reorder.cu:94-269 per group, shared quantize_group)
+// `staged()` runs once, right after the first batch of rows has been staged (every global load of that batch has landed): a caller
+// with loads of its own that the compiler does not track (mx_gemm_stream.hip's DMA ring) issues them there, so that they fly during
+// the arithmetic and the compiler's own wait counts never have to cover them.
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+template <int NT, class Hook = NoHook>
+__device__ __forceinline__ LdsMap quantize_rows_to_lds(const QuantIn &a, uint8_t *smem, Hook staged = Hook()) {
+    const int Kt = a.K[0] + a.K[1] + a.K[2], Gt = Kt >> 5;
+    const int gN = a.K[0] >> 5, gS = a.K[1] >> 5;
+    const int pN = a.K[0] >> 1, pS = (a.K[1] >> 2) * 3, pO = a.K[2];      // packed bytes per row and segment
+    uint8_t *stage = smem;
+    uint8_t *opN = stage + (size_t)a.stage_rows * Kt * 2, *opS = opN + a.M * pN, *opO = opS + a.M * pS;
+    uint8_t *scales = opO + a.M * pO;
+
+    // ---- phase 1: quantize the M activation rows into LDS (reorder.cu:94-269 per group, shared quantize_group) ----
+    // stage_rows rows are staged at a time and their (row, group) pairs are spread over all 512 threads
+    auto load_ix = [&](int g, uint32_t (&ix)[16]) {
+        const uint4 *p = reinterpret_cast<const uint4 *>(a.idx + (size_t)g * 32);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint4 q = p[i];
+            ix[4 * i] = (q.x << 1) & 0xFFFEFFFEu;      // byte offsets into the staged row, two per register
+            ix[4 * i + 1] = (q.y << 1) & 0xFFFEFFFEu;
+            ix[4 * i + 2] = (q.z << 1) & 0xFFFEFFFEu;
+            ix[4 * i + 3] = (q.w << 1) & 0xFFFEFFFEu;
+        }
+    };
+    for (int r0 = 0; r0 < a.M; r0 += a.stage_rows) {
+        const int nr = (a.M - r0) < a.stage_rows ? (a.M - r0) : a.stage_rows;
+        // the indices of this thread's first (row, group) pair are requested BEFORE the rows are staged, so the two global
+        // round trips overlap
+        uint32_t ix[16];
+        const int t0 = threadIdx.x;
+        if (t0 < nr * Gt) load_ix(t0 % Gt, ix);
+        const uint4 *grow = reinterpret_cast<const uint4 *>(a.X + (size_t)r0 * Kt);
+        for (int c = threadIdx.x; c < nr * (Kt >> 3); c += NT) reinterpret_cast<uint4 *>(stage)[c] = grow[c];
+        __syncthreads();
+        if (r0 == 0) staged();
+        for (int t = t0; t < nr * Gt; t += NT) {
+            const int rr = t / Gt, g = t - rr * Gt, r = r0 + rr;
+            const uint8_t *row = stage + (size_t)rr * Kt * 2;
+            if (t != t0) load_ix(g, ix);
+            uint32_t byte;
+            if (g < gN) byte = quantize_group<EL_FP4>(row, ix, opN + r * pN + g * 16);
+            else if (g < gN + gS) byte = quantize_group<EL_FP6>(row, ix, opS + r * pS + (g - gN) * 24);
+            else byte = quantize_group<EL_FP8>(row, ix, opO + r * pO + (g - gN - gS) * 32);
+            scales[r * Gt + g] = (uint8_t)byte;
+        }
+        __syncthreads();
+    }
+
+    LdsMap m;
+    m.opN = opN; m.opS = opS; m.opO = opO; m.scales = scales;
+    m.pN = pN; m.pS = pS; m.pO = pO; m.Gt = Gt; m.gN = gN; m.gS = gS;
+    return m;
+}
+
+}  // namespace dq
+}  // namespace mm

@@ -38,6 +38,7 @@
 #include <utility>
 
 #include "mx_common.h"
+#include "mx_decode_quant.h"
 #include "mx_kernels.h"
 
 namespace mm {
@@ -117,18 +118,25 @@ template <> struct Frag<2> { typedef v8i type; static constexpr int HW = HW_FP8;
 // g is a[4 (g F T16 + i) .. + 3].  Through the builtin -- or through asm on compiler-owned registers -- hipcc copied the three
 // accumulator sets at the joins of the segment branch (8-16 moves per step).  s_nop 1: two wait states between a just-written
 // source VGPR (the scale shift) and the MFMA -- hipcc pads nothing in front of an asm statement.  Scale bytes: byte 0 of sx / sw.
-#define MM_STREAM_ACC "a0","a1","a2","a3","a4","a5","a6","a7","a8","a9","a10","a11","a12","a13","a14","a15","a16","a17","a18","a19","a20","a21","a22","a23", \
-                      "a24","a25","a26","a27","a28","a29","a30","a31","a32","a33","a34","a35","a36","a37","a38","a39","a40","a41","a42","a43","a44","a45","a46","a47"
-template <int XEL, int WEL, int TILE>
+#define MM_STREAM_ACC12 "a0","a1","a2","a3","a4","a5","a6","a7","a8","a9","a10","a11"
+#define MM_STREAM_ACC24 MM_STREAM_ACC12,"a12","a13","a14","a15","a16","a17","a18","a19","a20","a21","a22","a23"
+#define MM_STREAM_ACC48 MM_STREAM_ACC24,"a24","a25","a26","a27","a28","a29","a30","a31","a32","a33","a34","a35","a36","a37","a38","a39","a40","a41","a42","a43","a44","a45","a46","a47"
+// (NACC = 12 F T16 accumulator registers: the clobber list names exactly those, the rest of the register file stays the compiler's)
+#define MM_STREAM_ASM_ACC(NACC, ...)                                                  \
+    do {                                                                              \
+        if constexpr ((NACC) <= 12) { MM_DEVICE_ONLY(asm volatile(__VA_ARGS__ : MM_STREAM_ACC12);) }       \
+        else if constexpr ((NACC) <= 24) { MM_DEVICE_ONLY(asm volatile(__VA_ARGS__ : MM_STREAM_ACC24);) }  \
+        else { MM_DEVICE_ONLY(asm volatile(__VA_ARGS__ : MM_STREAM_ACC48);) }                              \
+    } while (0)
+template <int XEL, int WEL, int TILE, int NACC>
 __device__ __forceinline__ void mfma16(const typename Frag<XEL>::type &x, const typename Frag<WEL>::type &w, int sx, int sw) {
-    static_assert(TILE < 12, "a[0:47]");
-    MM_DEVICE_ONLY(asm volatile("s_nop 1\n\tv_mfma_scale_f32_16x16x128_f8f6f4 a[%c6:%c7], %0, %1, a[%c6:%c7], %2, %3 op_sel_hi:[0,0,0] cbsz:%c4 blgp:%c5"
-                                :
-                                : "v"(x), "v"(w), "v"(sx), "v"(sw), "i"(Frag<XEL>::HW), "i"(Frag<WEL>::HW), "i"(4 * TILE), "i"(4 * TILE + 3)
-                                : MM_STREAM_ACC);)
+    static_assert(4 * TILE + 3 < NACC && NACC <= 48, "a[0:47]");
+    MM_STREAM_ASM_ACC(NACC, "s_nop 1\n\tv_mfma_scale_f32_16x16x128_f8f6f4 a[%c6:%c7], %0, %1, a[%c6:%c7], %2, %3 op_sel_hi:[0,0,0] cbsz:%c4 blgp:%c5"
+                      :
+                      : "v"(x), "v"(w), "v"(sx), "v"(sw), "i"(Frag<XEL>::HW), "i"(Frag<WEL>::HW), "i"(4 * TILE), "i"(4 * TILE + 3));
 }
-template <int REG>
-__device__ __forceinline__ void acc_zero() { MM_DEVICE_ONLY(asm volatile("v_accvgpr_write_b32 a[%c0], 0" ::"i"(REG) : MM_STREAM_ACC);) }
+template <int REG, int NACC>
+__device__ __forceinline__ void acc_zero() { MM_STREAM_ASM_ACC(NACC, "v_accvgpr_write_b32 a[%c0], 0" : : "i"(REG)); }
 template <int REG>
 __device__ __forceinline__ float acc_read() {
     float r = 0.0f;
@@ -141,11 +149,12 @@ __device__ __forceinline__ void static_for(Fn &&fn) {
 }
 
 // one slot of a wave's LDS ring: F weight tiles (one 1 KB piece each with fp4 weights, two otherwise), T16 activation tiles of two pieces
-template <int F, int T16, bool W4>
+// (QUANT: the workgroup quantizes the activation rows itself, mx_decode_quant.h -- no activation tiles, no activation scale atom)
+template <int F, int T16, bool W4, bool QUANT = false>
 struct Ring {
     static constexpr int WP = W4 ? 1 : 2;
-    static constexpr int W_BYTES = F * WP * 1024, X_BYTES = T16 * 2048, SLOT = W_BYTES + X_BYTES;
-    static constexpr int LOADS = ((MM_STREAM_DBG & 16) ? 0 : F * WP) + ((MM_STREAM_DBG & 1) ? 0 : 2 * T16) + ((MM_STREAM_DBG & 2) ? 0 : 2);
+    static constexpr int W_BYTES = F * WP * 1024, X_BYTES = QUANT ? 0 : T16 * 2048, SLOT = W_BYTES + X_BYTES;
+    static constexpr int LOADS = ((MM_STREAM_DBG & 16) ? 0 : F * WP) + ((MM_STREAM_DBG & 1) || QUANT ? 0 : 2 * T16) + ((MM_STREAM_DBG & 2) ? 0 : (QUANT ? 1 : 2));
 };
 
 // chunks per row of a segment's 128-deep slab: fp4 4, fp6 6, fp8 8 (x 16 bytes)
@@ -161,12 +170,18 @@ __device__ unsigned long long *g_stream_clock;
 #define MM_STAMP(i) do { } while (0)
 #endif
 
-template <int F, int T16, int D, int NW, bool W4>
-__device__ __forceinline__ void stream_body(const GemmArgs &a) {
+// QUANT (mm_qlinear_decode, M <= 8): X / SFX of `a` are unused; the workgroup quantizes the bf16 rows of `qi` into LDS itself, after
+// its first batch of rows is staged it requests its first D slabs of weights, and the activation fragments and scales of a slab come
+// from that LDS copy (rows in the reference's packed layout, as in qlinear_decode.hip).  `qbytes` = the quantization's LDS range in
+// front of the rings.
+template <int F, int T16, int D, int NW, bool W4, bool QUANT = false>
+__device__ __forceinline__ void stream_body(const GemmArgs &a, const dq::QuantIn &qi = dq::QuantIn(), int qbytes = 0) {
     static_assert(T16 <= 2, "token rows 32 .. 63 sit in row group 1 of the activation scale atoms: one more scale dword per slab");
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];  // the waves' rings [NW][D][Ring::SLOT], then the reduction image
+    static_assert(!QUANT || T16 == 1, "M <= 8");
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem_all[];  // [QUANT: staged rows | quantized rows | scale bytes] the waves' rings [NW][D][Ring::SLOT]; then the reduction image over the rings
+    uint8_t *const smem = smem_all + qbytes;
     MM_STAMP(0);
-    using RG = Ring<F, T16, W4>;
+    using RG = Ring<F, T16, W4, QUANT>;
     static_assert((D - 1) * RG::LOADS < 64, "vmcnt is a 6-bit counter");
     constexpr int BN = 16 * F, ACC = F * T16, NT = 64 * NW;
     const int n0 = blockIdx.x * BN;
@@ -198,9 +213,11 @@ __device__ __forceinline__ void stream_body(const GemmArgs &a) {
         wpitch[g] = ns[g] * wc * 16;
         // (the workgroup's own rows as the descriptor's range: rows past N read as zeros, offsets stay small)
         rw[g] = make_rsrc(a.W[g] + (size_t)n0 * (size_t)wpitch[g], (unsigned)wrows * (unsigned)wpitch[g]);
-        rx[g] = make_rsrc(a.X[g], (unsigned)a.M * (unsigned)xpitch[g]);
         rsw[g] = make_rsrc(a.SFW[g], (unsigned)a.sfw_row_tiles * (unsigned)ns[g] * 512u);
-        rsx[g] = make_rsrc(a.SFX[g], (unsigned)a.sfx_row_tiles * (unsigned)ns[g] * 512u);
+        if constexpr (!QUANT) {
+            rx[g] = make_rsrc(a.X[g], (unsigned)a.M * (unsigned)xpitch[g]);
+            rsx[g] = make_rsrc(a.SFX[g], (unsigned)a.sfx_row_tiles * (unsigned)ns[g] * 512u);
+        }
         wva[g] = ra[gw] * wpitch[g] + ca[gw] * 16;
         wvb[g] = vb[gw] ? rb[gw] * wpitch[g] + cb[gw] * 16 : OOB;
         xva[g] = ra[g] * xpitch[g] + ca[g] * 16;
@@ -225,7 +242,7 @@ __device__ __forceinline__ void stream_body(const GemmArgs &a) {
     const int rd8a = (li >> 3) * 1024 + (8 * (li & 7) + (h ^ s8)) * 16, rd8b = (li >> 3) * 1024 + (8 * (li & 7) + ((4 + h) ^ s8)) * 16;
 
     static_assert(12 * ACC <= 48, "a[0:47]");
-    static_for<12 * ACC>([&](auto r_) { acc_zero<decltype(r_)::value>(); });
+    static_for<12 * ACC>([&](auto r_) { acc_zero<decltype(r_)::value, 12 * ACC>(); });
 
     // slab s of segment G into slot d: RG::LOADS vector-memory instructions, whatever the segment
     auto issue_g = [&](Slot &q, int d, auto G_, int s) {
@@ -234,7 +251,7 @@ __device__ __forceinline__ void stream_body(const GemmArgs &a) {
         // the scale atoms first: they come from L2 and would otherwise queue behind the slab's weight tiles
         if constexpr (!(MM_STREAM_DBG & 2)) {
             q.sw = load_atom(rsw[G], sf_lane, (s + (n0 >> 7) * ns[G]) * 512);
-            q.sx = load_atom(rsx[G], sf_lane, s * 512);
+            if constexpr (!QUANT) q.sx = load_atom(rsx[G], sf_lane, s * 512);
         }
         if constexpr (!(MM_STREAM_DBG & 16)) {
 #pragma unroll
@@ -243,7 +260,7 @@ __device__ __forceinline__ void stream_body(const GemmArgs &a) {
                 if constexpr (!W4) dma16(rw[G], wvb[G], s * WC * 16 + 16 * f * wpitch[G], base + f * RG::WP * 1024 + 1024);
             }
         }
-        if constexpr (!(MM_STREAM_DBG & 1)) {
+        if constexpr (!(MM_STREAM_DBG & 1) && !QUANT) {
 #pragma unroll
             for (int t = 0; t < T16; ++t) {
                 dma16(rx[G], xva[G], s * XC * 16 + 16 * t * xpitch[G], base + RG::W_BYTES + t * 2048);
@@ -264,24 +281,41 @@ __device__ __forceinline__ void stream_body(const GemmArgs &a) {
             return v8i{p[0], p[1], p[2], p[3], p2[0], p2[1], p2[2], p2[3]};
         }
     };
-    auto consume_g = [&](const Slot &q, int d, auto G_) {
+    // QUANT: this lane's row of the workgroup's own quantized activations (rows past M: row 0 again -- their outputs are never stored)
+    dq::LdsMap L = {};
+    const uint8_t *qx[3] = {nullptr, nullptr, nullptr}, *qs[3] = {nullptr, nullptr, nullptr};
+    auto consume_g = [&](const Slot &q, int d, auto G_, int s) {
         constexpr int G = decltype(G_)::value, GW = W4 ? 0 : G;
         const uint8_t *base = ringp + d * RG::SLOT;
         // scales: the dword of (row, row group) from the lane that loaded it, shifted to this lane's K block
         int sx[T16], sw[F];
 #pragma unroll
         for (int f = 0; f < F; ++f) sw[f] = __builtin_amdgcn_ds_bpermute(sfw_src[f], sfw_hi[f] ? q.sw[1] : q.sw[0]) >> sh;
-#pragma unroll
-        for (int t = 0; t < T16; ++t) sx[t] = __builtin_amdgcn_ds_bpermute(sfx_src[t], q.sx[0]) >> sh;
         typename Frag<G>::type xv[T16];
         typename Frag<GW>::type wv[F];
+        if constexpr (QUANT) {
+            sx[0] = (int)(*reinterpret_cast<const uint32_t *>(qs[G] + 4 * s) >> sh);
+            const uint8_t *r = qx[G] + s * (chunks_of(G) * 16);          // (qx: row base + this lane's K block: 16 h, 24 h, 16 h)
+            if constexpr (G == 0) {
+                xv[0] = *reinterpret_cast<const v4i *>(r);
+            } else if constexpr (G == 1) {
+                const v2i p0 = *reinterpret_cast<const v2i *>(r), p1 = *reinterpret_cast<const v2i *>(r + 8), p2 = *reinterpret_cast<const v2i *>(r + 16);
+                xv[0] = v6i{p0[0], p0[1], p1[0], p1[1], p2[0], p2[1]};
+            } else {
+                const v4i p = *reinterpret_cast<const v4i *>(r), p2 = *reinterpret_cast<const v4i *>(r + 64);
+                xv[0] = v8i{p[0], p[1], p[2], p[3], p2[0], p2[1], p2[2], p2[3]};
+            }
+        } else {
 #pragma unroll
-        for (int t = 0; t < T16; ++t) xv[t] = frag(base + RG::W_BYTES + t * 2048, std::integral_constant<int, G>{});
+            for (int t = 0; t < T16; ++t) sx[t] = __builtin_amdgcn_ds_bpermute(sfx_src[t], q.sx[0]) >> sh;
+#pragma unroll
+            for (int t = 0; t < T16; ++t) xv[t] = frag(base + RG::W_BYTES + t * 2048, std::integral_constant<int, G>{});
+        }
 #pragma unroll
         for (int f = 0; f < F; ++f) wv[f] = frag(base + f * RG::WP * 1024, std::integral_constant<int, GW>{});
         static_for<ACC>([&](auto i_) {
             constexpr int i = decltype(i_)::value, f = i / T16, t = i % T16;
-            if constexpr (!(MM_STREAM_DBG & 4)) mfma16<G, GW, G * ACC + i>(xv[t], wv[f], sx[t], sw[f]);
+            if constexpr (!(MM_STREAM_DBG & 4)) mfma16<G, GW, G * ACC + i, 12 * ACC>(xv[t], wv[f], sx[t], sw[f]);
             else { MM_DEVICE_ONLY(asm volatile("" ::"v"(xv[t]), "v"(wv[f]), "v"(sx[t]), "v"(sw[f]));) }
         });
     };
@@ -292,21 +326,37 @@ __device__ __forceinline__ void stream_body(const GemmArgs &a) {
         else issue_g(q, d, std::integral_constant<int, 2>{}, j - c2);
     };
     auto consume = [&](const Slot &q, int d, int j) {
-        if (j < c1) consume_g(q, d, std::integral_constant<int, 0>{});
-        else if (j < c2) consume_g(q, d, std::integral_constant<int, 1>{});
-        else consume_g(q, d, std::integral_constant<int, 2>{});
+        if (j < c1) consume_g(q, d, std::integral_constant<int, 0>{}, j);
+        else if (j < c2) consume_g(q, d, std::integral_constant<int, 1>{}, j - c1);
+        else consume_g(q, d, std::integral_constant<int, 2>{}, j - c2);
     };
 
     // this wave's slabs: j = wave + NW * i, i = 0 .. cnt-1; `shift` phantom steps in front make the step count a multiple of D
     const int cnt = wave < T ? (T - wave + NW - 1) / NW : 0;
+    const int rounds = (cnt + D - 1) / D, shift = rounds * D - cnt;
+    auto slab_of = [&](int step) { const int i = step - shift; return wave + NW * (i > 0 ? i : 0); };
+    Slot q[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) q[d].sw = q[d].sx = v2i{0, 0};
+    auto prime = [&]() {
+        if (cnt > 0) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) issue(q[d], d, slab_of(d));
+        }
+    };
+    if constexpr (QUANT) {
+        L = dq::quantize_rows_to_lds<NT>(qi, smem_all, prime);
+        const int rr = li < a.M ? li : 0;
+        qx[0] = L.opN + rr * L.pN + 16 * h;
+        qx[1] = L.opS + rr * L.pS + 24 * h;
+        qx[2] = L.opO + rr * L.pO + 16 * h;
+        qs[0] = L.scales + rr * L.Gt;
+        qs[1] = qs[0] + L.gN;
+        qs[2] = qs[1] + L.gS;
+    } else {
+        prime();
+    }
     if (cnt > 0) {
-        const int rounds = (cnt + D - 1) / D, shift = rounds * D - cnt;
-        auto slab_of = [&](int step) { const int i = step - shift; return wave + NW * (i > 0 ? i : 0); };
-        Slot q[D];
-#pragma unroll
-        for (int d = 0; d < D; ++d) q[d].sw = q[d].sx = v2i{0, 0};
-#pragma unroll
-        for (int d = 0; d < D; ++d) issue(q[d], d, slab_of(d));
         MM_STAMP(1);
         for (int r = 0; r + 1 < rounds; ++r) {
 #pragma unroll
@@ -404,6 +454,40 @@ static hipError_t launch_one(const GemmArgs &a, hipStream_t stream) {
     return hipGetLastError();
 }
 
+// mm_qlinear_decode on the streaming kernel: the workgroup quantizes the M <= 8 rows itself (QUANT)
+template <int F, int D, int NW, bool W4>
+__global__ void __launch_bounds__(64 * NW) mx_qlinear_stream_kernel(GemmArgs a, dq::QuantIn qi, int qbytes) {
+    stream_body<F, 1, D, NW, W4, true>(a, qi, qbytes);
+}
+
+template <int F, int D, int NW, bool W4>
+static hipError_t launch_quant(const GemmArgs &a, dq::QuantIn qi, hipStream_t stream) {
+    const int present = (a.K[0] ? 1 : 0) + (a.K[1] ? 1 : 0) + (a.K[2] ? 1 : 0);
+    const size_t red_bytes = (size_t)NW * present * F * 4 * 64 * sizeof(float), ring_bytes = (size_t)NW * D * Ring<F, 1, W4, true>::SLOT;
+    const size_t tail = red_bytes > ring_bytes ? red_bytes : ring_bytes;
+    const size_t Kt = (size_t)a.K[0] + a.K[1] + a.K[2], ops = (dq::operand_bytes(a.M, a.K) + 15) & ~(size_t)15;
+    // staged bf16 rows: all M if two workgroups still fit a CU's 160 KB, else as many as one workgroup can hold (at least one)
+    constexpr size_t LDS_CU = 160 * 1024, LDS_WG = 156 * 1024;
+    size_t rows = a.M;
+    if (2 * (ops + tail + rows * Kt * 2) > LDS_CU) {
+        const size_t two = LDS_CU / 2 > ops + tail ? (LDS_CU / 2 - ops - tail) / (Kt * 2) : 0;
+        const size_t one = LDS_WG > ops + tail ? (LDS_WG - ops - tail) / (Kt * 2) : 0;
+        rows = two >= 1 ? two : one;
+        if (rows > (size_t)a.M) rows = a.M;
+    }
+    if (rows < 1) return hipErrorInvalidValue;
+    qi.stage_rows = (int)rows;
+    const size_t qbytes = rows * Kt * 2 + ops, lds = qbytes + tail;
+    static DynamicLdsOnce once;
+    if (lds > 65536) {
+        hipError_t e = once.ensure(reinterpret_cast<const void *>(mx_qlinear_stream_kernel<F, D, NW, W4>), (int)LDS_WG);
+        if (e != hipSuccess) return e;
+    }
+    const int blocks = (a.N + 16 * F - 1) / (16 * F);
+    MM_LAUNCH((mx_qlinear_stream_kernel<F, D, NW, W4>), dim3(blocks), dim3(64 * NW), lds, stream, a, qi, (int)qbytes);
+    return hipGetLastError();
+}
+
 }  // namespace stream
 
 #if MM_STREAM_CLOCK
@@ -420,6 +504,42 @@ bool mx_gemm_stream_supported(int M, int N, const int K[3], bool w4) {
     // (q/o at M = 1: 4.65 against 5.0-5.5 us; from M = 16 on the two meet)
     if (M <= 8 && (N + 15) / 16 <= device_cus() && K[0] + K[1] + K[2] <= 8192) return false;
     return true;
+}
+
+// 1 if mm_qlinear_decode can run on the streaming kernel (the quantized rows, one staged row and the rings fit a workgroup's LDS)
+bool qlinear_stream_supported(int M, int N, const int K[3]) {
+    static const int on = getenv("MICROMIX_DECODE_STREAM") ? atoi(getenv("MICROMIX_DECODE_STREAM")) : 1;   // kernel-developer override
+    // Measured against the first fused kernel (qlinear_decode.hip; tools/time_decode.py, profiles/r04_stream_ablation.txt section 8):
+    // it wins where N / 32 fills the CUs and one pass quantizes the rows (gate/up at M = 1 / 2 / 4: 12.5 / 11.8 / 14.3 -> 10.2 / 9.2 /
+    // 12.3 us) and loses on q/k/v/o (few workgroups: all start-up) and at M = 8 (two passes per workgroup: quantize + GEMM wins there).
+    const size_t Kt = (size_t)K[0] + K[1] + K[2];
+    if (!on || M < 1 || M > 4 || (N + 31) / 32 < device_cus()) return false;
+    return dq::operand_bytes(M, K) + Kt * 2 + 48 * 1024 + 64 <= 156 * 1024;
+}
+
+hipError_t launch_qlinear_stream(const void *X, const int16_t *idx, const uint8_t *const W[3], const uint8_t *const SFW[3], int M, int N,
+                                 const int K[3], bool w4, int round_per_segment, const void *bias, void *D, hipStream_t stream) {
+    using namespace stream;
+    GemmArgs a = {};
+    dq::QuantIn qi = {};
+    qi.X = (const uint16_t *)X;
+    qi.idx = idx;
+    qi.M = M;
+    for (int g = 0; g < 3; ++g) {
+        a.W[g] = W[g];
+        a.SFW[g] = SFW[g];
+        a.K[g] = qi.K[g] = K[g];
+    }
+    a.M = M;
+    a.N = N;
+    a.sfx_row_tiles = 1;
+    a.sfw_row_tiles = (N + 127) / 128;
+    a.round_per_segment = round_per_segment;
+    a.bias = (const uint16_t *)bias;
+    a.D = (uint16_t *)D;
+    const bool wide = (N + 31) / 32 >= device_cus();
+    if (wide) return w4 ? launch_quant<2, 2, 8, true>(a, qi, stream) : launch_quant<2, 2, 8, false>(a, qi, stream);
+    return w4 ? launch_quant<1, 3, 8, true>(a, qi, stream) : launch_quant<1, 3, 8, false>(a, qi, stream);
 }
 
 #ifndef MM_STREAM_SWEEP      // kernel-developer build: every (F, D, NW) combination, picked by MICROMIX_STREAM_CFG="F,D,NW"

@@ -12,7 +12,7 @@
 #ifndef MM_DECODE_DEPTH
 #define MM_DECODE_DEPTH 4   // weight slabs a wave requests at once (1 = one memory round trip per slab)
 #endif
-#include "mx_group_convert.h"
+#include "mx_decode_quant.h"
 #include "mx_kernels.h"
 
 namespace mm {
@@ -144,61 +144,12 @@ __device__ __forceinline__ void run_segment(v16f &acc, const uint8_t *xl, int xp
     }
 }
 
-// LDS map of both kernels: [staged bf16 rows | opN | opS | opO | scale bytes]
-struct LdsMap {
-    uint8_t *opN, *opS, *opO, *scales;
-    int pN, pS, pO, Gt, gN, gS;
-};
-
-// phase 1: quantize the M activation rows into LDS (reorder.cu:94-269 per group, shared quantize_group)
+using dq::LdsMap;
 __device__ __forceinline__ LdsMap quantize_rows_to_lds(const Args &a, uint8_t *smem) {
-    const int Kt = a.K[0] + a.K[1] + a.K[2], Gt = Kt >> 5;
-    const int gN = a.K[0] >> 5, gS = a.K[1] >> 5;
-    const int pN = a.K[0] >> 1, pS = (a.K[1] >> 2) * 3, pO = a.K[2];      // packed bytes per row and segment
-    uint8_t *stage = smem;
-    uint8_t *opN = stage + (size_t)a.stage_rows * Kt * 2, *opS = opN + a.M * pN, *opO = opS + a.M * pS;
-    uint8_t *scales = opO + a.M * pO;
-
-    // ---- phase 1: quantize the M activation rows into LDS (reorder.cu:94-269 per group, shared quantize_group) ----
-    // stage_rows rows are staged at a time and their (row, group) pairs are spread over all 512 threads
-    auto load_ix = [&](int g, uint32_t (&ix)[16]) {
-        const uint4 *p = reinterpret_cast<const uint4 *>(a.idx + (size_t)g * 32);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const uint4 q = p[i];
-            ix[4 * i] = (q.x << 1) & 0xFFFEFFFEu;      // byte offsets into the staged row, two per register
-            ix[4 * i + 1] = (q.y << 1) & 0xFFFEFFFEu;
-            ix[4 * i + 2] = (q.z << 1) & 0xFFFEFFFEu;
-            ix[4 * i + 3] = (q.w << 1) & 0xFFFEFFFEu;
-        }
-    };
-    for (int r0 = 0; r0 < a.M; r0 += a.stage_rows) {
-        const int nr = (a.M - r0) < a.stage_rows ? (a.M - r0) : a.stage_rows;
-        // the indices of this thread's first (row, group) pair are requested BEFORE the rows are staged, so the two global
-        // round trips overlap
-        uint32_t ix[16];
-        const int t0 = threadIdx.x;
-        if (t0 < nr * Gt) load_ix(t0 % Gt, ix);
-        const uint4 *grow = reinterpret_cast<const uint4 *>(a.X + (size_t)r0 * Kt);
-        for (int c = threadIdx.x; c < nr * (Kt >> 3); c += NT) reinterpret_cast<uint4 *>(stage)[c] = grow[c];
-        __syncthreads();
-        for (int t = t0; t < nr * Gt; t += NT) {
-            const int rr = t / Gt, g = t - rr * Gt, r = r0 + rr;
-            const uint8_t *row = stage + (size_t)rr * Kt * 2;
-            if (t != t0) load_ix(g, ix);
-            uint32_t byte;
-            if (g < gN) byte = quantize_group<EL_FP4>(row, ix, opN + r * pN + g * 16);
-            else if (g < gN + gS) byte = quantize_group<EL_FP6>(row, ix, opS + r * pS + (g - gN) * 24);
-            else byte = quantize_group<EL_FP8>(row, ix, opO + r * pO + (g - gN - gS) * 32);
-            scales[r * Gt + g] = (uint8_t)byte;
-        }
-        __syncthreads();
-    }
-
-    LdsMap m;
-    m.opN = opN; m.opS = opS; m.opO = opO; m.scales = scales;
-    m.pN = pN; m.pS = pS; m.pO = pO; m.Gt = Gt; m.gN = gN; m.gS = gS;
-    return m;
+    dq::QuantIn q;
+    q.X = a.X; q.idx = a.idx; q.M = a.M; q.stage_rows = a.stage_rows;
+    q.K[0] = a.K[0]; q.K[1] = a.K[1]; q.K[2] = a.K[2];
+    return dq::quantize_rows_to_lds<NT>(q, smem);
 }
 
 template <bool W4>
@@ -399,10 +350,7 @@ __global__ void __launch_bounds__(NT) qlinear_decode16_kernel(Args a) {
 
 // dynamic LDS: the quantized rows and scales of all M rows + as many staged bf16 rows as fit next to the 32 KB reduction buffer
 constexpr size_t DECODE_LDS_MAX = 126 * 1024;
-static size_t decode_operand_bytes(int M, const int K[3]) {   // quantized rows + their scale bytes
-    const size_t Kt = (size_t)K[0] + K[1] + K[2];
-    return (size_t)M * (K[0] / 2 + K[1] / 4 * 3 + K[2] + Kt / 32);
-}
+static size_t decode_operand_bytes(int M, const int K[3]) { return dq::operand_bytes(M, K); }
 
 // features per workgroup: 16 while 32 would leave half of the CUs without a workgroup
 static int decode_features(int N) { return 2 * ((N + 31) / 32) <= device_cus() ? 16 : 32; }
@@ -423,6 +371,7 @@ hipError_t launch_qlinear_decode(const void *X, const int16_t *idx, const uint8_
                                  int M, int N, const int K[3], bool w4, int round_per_segment, const void *bias, void *D,
                                  hipStream_t stream) {
     using namespace decode;
+    if (qlinear_stream_supported(M, N, K)) return launch_qlinear_stream(X, idx, W, SFW, M, N, K, w4, round_per_segment, bias, D, stream);
     Args a;
     a.X = (const uint16_t *)X;
     a.idx = idx;
