@@ -143,7 +143,7 @@ const char *mm_matmul_describe(int M, int N, int KN, int KS, int KO, int wmode, 
     if (M <= 0 || N <= 0 || KN < 0 || KS < 0 || KO < 0 || (KN % 128) || (KS % 128) || (KO % 128) || KN + KS + KO == 0) return "none";
     const int K[3] = {KN, KS, KO};
     if (M <= 64 && !mm::mx_gemm_small_m_uses_tiles(M, N, K, wmode == MM_W_FP4, workspace_bytes, (flags & MM_SPLIT_K_ALWAYS) != 0))
-        return mm::mx_gemm_stream_supported(M, N, K, wmode == MM_W_FP4) ? "mm::stream::mx_gemm_stream_kernel (weight streaming, M <= 32)"
+        return mm::mx_gemm_stream_supported(M, N, K, wmode == MM_W_FP4) ? "mm::stream::mx_gemm_stream_kernel (weight streaming, M <= 64)"
                                                                          : "mm::skinny::mx_gemm_skinny*_kernel (weight streaming, M <= 64)";
     return mm::describe_mx_gemm256(M, N, K, wmode == MM_W_FP4, workspace_bytes, (flags & MM_SPLIT_K_ALWAYS) != 0, (flags & MM_WS_TICKETS_ZEROED) != 0);
 }

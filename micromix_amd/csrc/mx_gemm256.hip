@@ -473,17 +473,20 @@ bool mx_gemm_small_m_uses_tiles(int M, int N, const int K[3], bool w4, size_t ws
     if (M <= 16 && !tiles_le16) return false;
     if (M <= 32) return (N + 31) / 32 > 3 * device_cus();
     if (M <= 32 || M > 64) return M > 64;
+    static const int mid_stream = env_int("MICROMIX_MID_M_STREAM", 0);      // kernel-developer override: 32 < M <= 64 always on the weight-streaming kernel
+    if (mid_stream) return false;
     if ((N + 31) / 32 > device_cus()) return true;
-    // 32 < M <= 64 on one round of 32 x 64 tiles (round 4; tools/_job history in profiles/r04_small_tiles.txt, (2048,128,1920), us):
-    // a workgroup of those tiles walks K = 4096 in ~9.8 us however many of them there are, the weight-streaming kernel needs
-    // 9.2 / 9.7 / 10.0 / 12.2 at M = 33 / 40 / 48 / 64 for N <= 4096 and 10.4 ... 12.3 at N = 6144 (more than half a round of its
-    // 32-feature workgroups).  So: M > 48 always, smaller M from N / 32 > CUs / 2 on.
+    // 32 < M <= 64 on one round of 32 x 64 tiles (round 4; profiles/r04_small_tiles.txt, (2048,128,1920), us): a workgroup of those
+    // tiles walks K = 4096 in ~9.8 us however many of them there are.  The second weight-streaming kernel (mx_gemm_stream.hip, three /
+    // four token tiles) takes 6.7 / 6.8 / 7.7 at M = 33 / 48 / 64 for N = 4096 and 14.0 / 14.7 / 17.3 on down_proj's K = 14336 (the
+    // two-launch split-K: 19.5), but 14.1-16.3 against the tiles' 13.5-14.0 at N = 14336: so the tiles from N / 32 > CUs / 2 on, the
+    // streaming kernel below, and the split-K plan only when the caller forces it.
     {
         static const int small16 = env_int("MICROMIX_SMALL_M_TILE16", 1);
         const int t16 = ((M + 31) / 32) * ((N + 63) / 64);
-        if (small16 && t16 <= device_cus() && (M > 48 || 2 * ((N + 31) / 32) > device_cus())) return true;
+        if (small16 && t16 <= device_cus() && 2 * ((N + 31) / 32) > device_cus()) return true;
     }
-    if (ws_bytes == 0) return false;
+    if (ws_bytes == 0 || !force_split) return false;
     const size_t need = mx_gemm_workspace_bytes(M, N, K, w4, force_split, false);   // (the in-kernel split starts above M = 64)
     return need > 0 && need <= ws_bytes;
 }

@@ -121,16 +121,19 @@ template <> struct Frag<2> { typedef v8i type; static constexpr int HW = HW_FP8;
 #define MM_STREAM_ACC12 "a0","a1","a2","a3","a4","a5","a6","a7","a8","a9","a10","a11"
 #define MM_STREAM_ACC24 MM_STREAM_ACC12,"a12","a13","a14","a15","a16","a17","a18","a19","a20","a21","a22","a23"
 #define MM_STREAM_ACC48 MM_STREAM_ACC24,"a24","a25","a26","a27","a28","a29","a30","a31","a32","a33","a34","a35","a36","a37","a38","a39","a40","a41","a42","a43","a44","a45","a46","a47"
+#define MM_STREAM_ACC96 MM_STREAM_ACC48,"a48","a49","a50","a51","a52","a53","a54","a55","a56","a57","a58","a59","a60","a61","a62","a63","a64","a65","a66","a67","a68","a69","a70","a71", \
+                        "a72","a73","a74","a75","a76","a77","a78","a79","a80","a81","a82","a83","a84","a85","a86","a87","a88","a89","a90","a91","a92","a93","a94","a95"
 // (NACC = 12 F T16 accumulator registers: the clobber list names exactly those, the rest of the register file stays the compiler's)
 #define MM_STREAM_ASM_ACC(NACC, ...)                                                  \
     do {                                                                              \
         if constexpr ((NACC) <= 12) { MM_DEVICE_ONLY(asm volatile(__VA_ARGS__ : MM_STREAM_ACC12);) }       \
         else if constexpr ((NACC) <= 24) { MM_DEVICE_ONLY(asm volatile(__VA_ARGS__ : MM_STREAM_ACC24);) }  \
-        else { MM_DEVICE_ONLY(asm volatile(__VA_ARGS__ : MM_STREAM_ACC48);) }                              \
+        else if constexpr ((NACC) <= 48) { MM_DEVICE_ONLY(asm volatile(__VA_ARGS__ : MM_STREAM_ACC48);) }  \
+        else { MM_DEVICE_ONLY(asm volatile(__VA_ARGS__ : MM_STREAM_ACC96);) }                              \
     } while (0)
 template <int XEL, int WEL, int TILE, int NACC>
 __device__ __forceinline__ void mfma16(const typename Frag<XEL>::type &x, const typename Frag<WEL>::type &w, int sx, int sw) {
-    static_assert(4 * TILE + 3 < NACC && NACC <= 48, "a[0:47]");
+    static_assert(4 * TILE + 3 < NACC && NACC <= 96, "a[0:95]");
     MM_STREAM_ASM_ACC(NACC, "s_nop 1\n\tv_mfma_scale_f32_16x16x128_f8f6f4 a[%c6:%c7], %0, %1, a[%c6:%c7], %2, %3 op_sel_hi:[0,0,0] cbsz:%c4 blgp:%c5"
                       :
                       : "v"(x), "v"(w), "v"(sx), "v"(sw), "i"(Frag<XEL>::HW), "i"(Frag<WEL>::HW), "i"(4 * TILE), "i"(4 * TILE + 3));
@@ -176,7 +179,7 @@ __device__ unsigned long long *g_stream_clock;
 // front of the rings.
 template <int F, int T16, int D, int NW, bool W4, bool QUANT = false>
 __device__ __forceinline__ void stream_body(const GemmArgs &a, const dq::QuantIn &qi = dq::QuantIn(), int qbytes = 0) {
-    static_assert(T16 <= 2, "token rows 32 .. 63 sit in row group 1 of the activation scale atoms: one more scale dword per slab");
+    static_assert(T16 <= 4, "64 token rows: row groups 0 and 1 of the activation scale atoms, both in the 8 bytes a lane loads");
     static_assert(!QUANT || T16 == 1, "M <= 8");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem_all[];  // [QUANT: staged rows | quantized rows | scale bytes] the waves' rings [NW][D][Ring::SLOT]; then the reduction image over the rings
     uint8_t *const smem = smem_all + qbytes;
@@ -235,13 +238,13 @@ __device__ __forceinline__ void stream_body(const GemmArgs &a, const dq::QuantIn
         sfw_src[f] = 4 * (2 * ((n0 + 16 * f + li) & 31) + (rg >> 1));
     }
 #pragma unroll
-    for (int t = 0; t < T16; ++t) sfx_src[t] = 4 * (2 * (16 * t + li));      // token rows < 32: row group 0
+    for (int t = 0; t < T16; ++t) sfx_src[t] = 4 * (2 * ((16 * t + li) & 31));   // token row 16 t + li: atom row (.. & 31), row group t >> 1
     // fragment reads: lane (row li, K block h) holds 16 B at chunk h (fp4), 24 B at byte 24 h (fp6), chunks h and 4 + h (fp8) of its row
     const int s8 = (li >> 1) & 7;
     const int rd4 = (4 * li + (h ^ (li >> 2))) * 16, rd6 = li * 96 + 24 * h;
     const int rd8a = (li >> 3) * 1024 + (8 * (li & 7) + (h ^ s8)) * 16, rd8b = (li >> 3) * 1024 + (8 * (li & 7) + ((4 + h) ^ s8)) * 16;
 
-    static_assert(12 * ACC <= 48, "a[0:47]");
+    static_assert(12 * ACC <= 96, "a[0:95]");
     static_for<12 * ACC>([&](auto r_) { acc_zero<decltype(r_)::value, 12 * ACC>(); });
 
     // slab s of segment G into slot d: RG::LOADS vector-memory instructions, whatever the segment
@@ -307,7 +310,7 @@ __device__ __forceinline__ void stream_body(const GemmArgs &a, const dq::QuantIn
             }
         } else {
 #pragma unroll
-            for (int t = 0; t < T16; ++t) sx[t] = __builtin_amdgcn_ds_bpermute(sfx_src[t], q.sx[0]) >> sh;
+            for (int t = 0; t < T16; ++t) sx[t] = __builtin_amdgcn_ds_bpermute(sfx_src[t], t >= 2 ? q.sx[1] : q.sx[0]) >> sh;
 #pragma unroll
             for (int t = 0; t < T16; ++t) xv[t] = frag(base + RG::W_BYTES + t * 2048, std::integral_constant<int, G>{});
         }
@@ -385,11 +388,45 @@ __device__ __forceinline__ void stream_body(const GemmArgs &a, const dq::QuantIn
         if (t == 12345.678f) a.D[0] = 1;
         return;
     }
-    // ---- cross-wave reduction: partial sums of the present segments side by side, one barrier ----
+    // ---- cross-wave reduction: the partial sums of the present segments side by side and one barrier; with eight 16 x 16 tiles per
+    //      wave (M > 32 on 32 features) one segment at a time through one image (the side-by-side image would not leave room for a
+    //      second workgroup on the CU) ----
     const int p0 = ns[0] ? 1 : 0, p1 = ns[1] ? 1 : 0, p2 = ns[2] ? 1 : 0, P = p0 + p1 + p2;
     constexpr int IMG = ACC * 4 * 64;                   // floats per wave and segment
+    constexpr bool SEQ = ACC >= 8;
+    constexpr int OUTS = ACC * 256, PER = (OUTS + NT - 1) / NT;
     float *const red = reinterpret_cast<float *>(smem);
-    {
+    float run[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) run[k] = 0.0f;
+    auto chain = [&](int k, float s) {      // D = bf16(segment sum + D): the reference's rounding between its chained GEMMs
+        s += run[k];
+        run[k] = a.round_per_segment ? bf16_bits_to_f32(f32_to_bf16_bits(s)) : s;
+    };
+    if constexpr (SEQ) {
+        static_for<3>([&](auto g_) {
+            constexpr int g = decltype(g_)::value;
+            const int present = g == 0 ? p0 : (g == 1 ? p1 : p2);
+            if (present) {
+                __syncthreads();       // every wave is done with its ring / the previous segment's image has been read
+                static_for<4 * ACC>([&](auto r_) {
+                    constexpr int r = decltype(r_)::value;      // register r & 3 of tile r >> 2
+                    red[(size_t)wave * IMG + r * 64 + lane] = acc_read<4 * g * ACC + r>();
+                });
+                __syncthreads();
+#pragma unroll
+                for (int k = 0; k < PER; ++k) {
+                    const int o = threadIdx.x + k * NT;
+                    float s = 0.0f;
+                    if (o < OUTS) {
+#pragma unroll
+                        for (int w = 0; w < NW; ++w) s += red[(size_t)w * IMG + o];
+                    }
+                    chain(k, s);
+                }
+            }
+        });
+    } else {
         __syncthreads();       // every wave is done with its ring: the reduction image reuses it
         float *mine = red + (size_t)wave * P * IMG;
         int slot = 0;
@@ -404,29 +441,33 @@ __device__ __forceinline__ void stream_body(const GemmArgs &a, const dq::QuantIn
                 ++slot;
             }
         });
-    }
-    __syncthreads();
-    MM_STAMP(3);
-    // output o = (i = f * T16 + t, r, l): token 16 t + 4 (l >> 4) + r, feature n0 + 16 f + (l & 15)
-    constexpr int OUTS = ACC * 256;
+        __syncthreads();
+        MM_STAMP(3);
 #pragma unroll
-    for (int o = threadIdx.x; o < OUTS; o += NT) {
-        float run = 0.0f;
-        for (int slot = 0; slot < P; ++slot) {
-            float s = 0.0f;
+        for (int k = 0; k < PER; ++k) {
+            const int o = threadIdx.x + k * NT;
+            if (o < OUTS) {
+                for (int sl = 0; sl < P; ++sl) {
+                    float s = 0.0f;
 #pragma unroll
-            for (int w = 0; w < NW; ++w) s += red[((size_t)w * P + slot) * IMG + o];
-            s += run;
-            run = a.round_per_segment ? bf16_bits_to_f32(f32_to_bf16_bits(s)) : s;
+                    for (int w = 0; w < NW; ++w) s += red[((size_t)w * P + sl) * IMG + o];
+                    chain(k, s);
+                }
+            }
         }
+    }
+    // output o = (i = f * T16 + t, r, l): token 16 t + 4 (l >> 4) + r, feature n0 + 16 f + (l & 15)
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int o = threadIdx.x + k * NT;
         const int l = o & 63, r = (o >> 6) & 3, i = o >> 8;
         const int f = i / T16, t = i % T16;
         const int m = 16 * t + 4 * (l >> 4) + r, n = n0 + 16 * f + (l & 15);
-        if (m < a.M && n < a.N) {
+        if (o < OUTS && m < a.M && n < a.N) {
             if (a.out_f32) {
-                reinterpret_cast<float *>(a.D)[(size_t)m * a.N + n] = run;
+                reinterpret_cast<float *>(a.D)[(size_t)m * a.N + n] = run[k];
             } else {
-                uint32_t b = f32_to_bf16_bits(run);
+                uint32_t b = f32_to_bf16_bits(run[k]);
                 if (a.bias != nullptr) b = f32_to_bf16_bits(bf16_bits_to_f32(b) + bf16_bits_to_f32(a.bias[n]));
                 a.D[(size_t)m * a.N + n] = (uint16_t)b;
             }
@@ -441,11 +482,11 @@ __global__ void __launch_bounds__(64 * NW) mx_gemm_stream_kernel(GemmArgs a) { s
 template <int F, int T16, int D, int NW, bool W4>
 static hipError_t launch_one(const GemmArgs &a, hipStream_t stream) {
     const int present = (a.K[0] ? 1 : 0) + (a.K[1] ? 1 : 0) + (a.K[2] ? 1 : 0);
-    const int red_bytes = NW * present * F * T16 * 4 * 64 * (int)sizeof(float), stage_bytes = NW * D * Ring<F, T16, W4>::SLOT;
+    const int red_bytes = NW * (F * T16 >= 8 ? 1 : present) * F * T16 * 4 * 64 * (int)sizeof(float), stage_bytes = NW * D * Ring<F, T16, W4>::SLOT;
     const int lds = red_bytes > stage_bytes ? red_bytes : stage_bytes;
     static DynamicLdsOnce once;
     if (lds > 65536) {
-        constexpr int MAX_RED = NW * 3 * F * T16 * 1024, MAX_STAGE = NW * D * Ring<F, T16, W4>::SLOT;
+        constexpr int MAX_RED = NW * (F * T16 >= 8 ? 1 : 3) * F * T16 * 1024, MAX_STAGE = NW * D * Ring<F, T16, W4>::SLOT;
         hipError_t e = once.ensure(reinterpret_cast<const void *>(mx_gemm_stream_kernel<F, T16, D, NW, W4>), MAX_RED > MAX_STAGE ? MAX_RED : MAX_STAGE);
         if (e != hipSuccess) return e;
     }
@@ -499,7 +540,7 @@ extern "C" int mm_diag_set_stream_clock(void *buf) {
 bool mx_gemm_stream_supported(int M, int N, const int K[3], bool w4) {
     static const int on = getenv("MICROMIX_STREAM") ? atoi(getenv("MICROMIX_STREAM")) : 1;   // kernel-developer override
     (void)w4;
-    if (!on || M > 32) return false;
+    if (!on || M > 64) return false;
     // few features, short K, a handful of tokens (q/k/v/o at M <= 8): the launch is all start-up, and the first kernel's is shorter
     // (q/o at M = 1: 4.65 against 5.0-5.5 us; from M = 16 on the two meet)
     if (M <= 8 && (N + 15) / 16 <= device_cus() && K[0] + K[1] + K[2] <= 8192) return false;
@@ -558,7 +599,7 @@ hipError_t launch_mx_gemm_stream(const GemmArgs &a, bool w4, hipStream_t stream)
     static const bool have = getenv("MICROMIX_STREAM_CFG") && sscanf(getenv("MICROMIX_STREAM_CFG"), "%d,%d,%d", &cf, &cd, &cn) == 3;
     if (have) {
 #define MM_TRY(F_, D_, NW_)                                                                              \
-    if (cf == F_ && cd == D_ && cn == NW_) return a.M <= 16 ? MM_STREAM(F_, 1, D_, NW_) : MM_STREAM(F_, 2, D_, NW_);
+    if (cf == F_ && cd == D_ && cn == NW_) return a.M <= 16 ? MM_STREAM(F_, 1, D_, NW_) : (a.M <= 32 ? MM_STREAM(F_, 2, D_, NW_) : MM_STREAM(F_, 4, D_, NW_));
         if (cf == 4 && cd == 4 && cn == 4 && a.M <= 16) return MM_STREAM(4, 1, 4, 4);
         if (cf == 4 && cd == 3 && cn == 8 && a.M <= 16) return MM_STREAM(4, 1, 3, 8);
         if (cf == 4 && cd == 4 && cn == 8 && a.M <= 16) return MM_STREAM(4, 1, 4, 8);
@@ -571,7 +612,10 @@ hipError_t launch_mx_gemm_stream(const GemmArgs &a, bool w4, hipStream_t stream)
     // (slots, waves) from sweeps on three boxes (profiles/r04_stream_ablation.txt, section 7): more waves with a shallow ring beat fewer
     // with a deep one; 32 tokens x 32 features: four waves, so that two workgroups fit a CU's LDS
     if (a.M <= 16) return wide ? MM_STREAM(2, 1, 2, 8) : MM_STREAM(1, 1, 3, 8);
-    return wide ? MM_STREAM(2, 2, 3, 4) : MM_STREAM(1, 2, 3, 8);
+    if (a.M <= 32) return wide ? MM_STREAM(2, 2, 3, 4) : MM_STREAM(1, 2, 3, 8);
+    // 33 .. 64 tokens: three / four token tiles; two slots of 8 / 10 KB and four waves, so that two workgroups fit a CU's LDS
+    if (a.M <= 48) return wide ? MM_STREAM(2, 3, 2, 4) : MM_STREAM(1, 3, 2, 8);
+    return wide ? MM_STREAM(2, 4, 2, 4) : MM_STREAM(1, 4, 2, 8);
 #undef MM_STREAM
 }
 

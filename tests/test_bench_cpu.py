@@ -39,7 +39,8 @@ def test_matmul_describe_names_the_dispatch():
     assert "g256" in d(4096, 4096, 0, 0, 4096, 1, 0, 0) and "256 workgroups" in d(4096, 4096, 0, 0, 4096, 1, 0, 0)
     assert "last 8 tile columns" in d(4096, 14336, 0, 0, 4096, 1, 0, 0)        # 896 tiles = 3.5 rounds: tail balancing
     assert "mx_gemm_stream_kernel" in d(16, 4096, 0, 0, 4096, 1, 0, 0) and "mx_gemm_stream_kernel" in d(1, 14336, 2048, 128, 1920, 1, 0, 0)
-    assert "skinny" in d(1, 4096, 0, 0, 4096, 1, 0, 0) and "skinny" in d(48, 4096, 0, 0, 4096, 1, 0, 0)   # all start-up / 32 < M <= 48
+    assert "skinny" in d(1, 4096, 0, 0, 4096, 1, 0, 0) and "mx_gemm_stream_kernel" in d(64, 4096, 0, 0, 4096, 1, 0, 0)   # all start-up / 32 < M <= 64, few features
+    assert "g32n" in d(64, 14336, 0, 0, 4096, 1, 0, 0)                                                                    # ... many features: tiles
     assert "<false,false>" in d(4096, 4096, 0, 0, 4096, 0, 0, 0)               # matching-precision weights
     assert d(0, 4096, 0, 0, 4096, 1, 0, 0) == "none" and d(4096, 4096, 100, 0, 0, 1, 0, 0) == "none"
     assert "split-K" in d(192, 256, 12288, 1024, 1024, 1, _lib.MM_SPLIT_K_ALWAYS, 1 << 30)

@@ -52,7 +52,7 @@ SPLIT_SHAPES = [
     (65, 256, 512, (0, 0, 512)), (130, 256, 4096, (2048, 1024, 1024)), (128, 1024, 4096, (0, 0, 4096)),
     (256, 512, 1792, (1024, 128, 640)), (200, 300, 2048, (128, 1792, 128)), (512, 2048, 1024, (512, 512, 0)),
     (96, 640, 5120, (4096, 512, 512)), (192, 256, 14336, (12288, 1024, 1024)), (129, 264, 768, (256, 256, 256)),
-    (48, 256, 14336, (12288, 1024, 1024)),     # 32 < M <= 64 with a long K: split-K tiles instead of the skinny kernel
+    (48, 256, 14336, (12288, 1024, 1024)),     # 32 < M <= 64 with a long K: split-K tiles when forced, the weight-streaming kernel otherwise
 ]
 
 
@@ -443,8 +443,8 @@ def test_poisoned_ticket_and_ws_reset(dev):
 # one problem per tile kernel of mx_gemm256.hip (the dispatch is asserted, so a change of plan_tiles cannot silently drop one):
 # ragged M and N, all three segments, both weight modes; oracle on a row sample over every column
 TILE_KERNELS = [
-    # (and 32 < M <= 64 from M > 48 / N > 4096 on, instead of the weight-streaming kernel)
-    ("g16", "32x64", 100, 4090), ("g16", "32x64", 128, 4000), ("g16", "32x64", 64, 4096), ("g16", "32x64", 40, 6144),     # 64 x 64 tiles would fill at most half of the CUs: 32 x 64 tiles
+    # (and 32 < M <= 64 from N > 4096 on, instead of the weight-streaming kernel)
+    ("g16", "32x64", 100, 4090), ("g16", "32x64", 128, 4000), ("g16", "32x64", 64, 6144), ("g16", "32x64", 40, 6144),     # 64 x 64 tiles would fill at most half of the CUs: 32 x 64 tiles
     ("g32n", "64x64", 250, 4000), ("g32n", "64x64", 50, 8230),   # 32 < M <= 64 and more than a round of skinny workgroups: tiles
     ("g32", "64x128", 500, 4090), ("g64", "128x128", 700, 4090),
     ("g128", "128x256", 1500, 4000), ("g256", "256x256", 4000, 4090),
@@ -493,6 +493,8 @@ STREAM_CASES = [
     (25, 4100, (0, 256, 2048)),            # two token tiles, no fp4 segment
     (32, 300, (3072, 896, 128)),           # two token tiles, 32 slabs
 ]
+# 32 < M <= 64 (three / four token tiles; the dispatch sends only some of these shapes to the streaming kernel, so it is forced through
+# MICROMIX_MID_M_STREAM in a child process: tests/test_stream_mid_m_gpu.py)
 
 
 @pytest.mark.parametrize("wmode", ("w4", "w"))
