@@ -1,36 +1,38 @@
-// Weight-streaming three-segment MX GEMM for M <= 32 on gfx950, second generation (round 4): the decode / small-batch path of
-// mm_matmul.  Same arithmetic and reference citations as mx_gemm_skinny.hip (gemm.cu:26-78: D = bf16(N); D = bf16(S + D);
-// D = bf16(O + D), fp32 accumulation inside a segment).
+// Weight-streaming three-segment MX GEMM for M <= 64 on gfx950, second generation (round 4): the decode / small-batch path of
+// mm_matmul, and -- with the quantization of the activation rows inside every workgroup -- of mm_qlinear_decode.  Same arithmetic and
+// reference citations as mx_gemm_skinny.hip (gemm.cu:26-78: D = bf16(N); D = bf16(S + D); D = bf16(O + D), fp32 accumulation inside
+// a segment).
 //
 // Why a second kernel.  A launch that ONLY streams the 29 MB of gate_proj's packed weights takes 3.7 us with lane-contiguous loads
 // and 4.9 us with the first kernel's pattern (lane = weight row: 64 separate 16-byte requests per instruction; tools/stream_floor.py;
 // the weights of one layer stay in the Infinity Cache between back-to-back launches).  The first weight-streaming kernel needed
-// 11.6 us at M = 16.  Ablations on a register-ring version of it (profiles/r04_stream_ablation.txt) showed that the time is the sum
-// of its vector-memory instructions, at 30-45 cycles each, whatever they fetch: weights 2.8 us, activations 3.3 us, the three scale
-// dwords per slab 2.7 us -- not a chain of round trips.  A wave instruction whose lanes read consecutive bytes costs bytes / 64
-// cycles instead.  So here EVERY load is lane-contiguous and the MFMA's (lane = row) operand layout is made in LDS:
-//  * one workgroup = 16 * F output features x all tokens, its 8 waves split K: the 128-deep slabs of N | S | O are numbered
-//    through (j = 0 .. T-1) and slab j goes to wave j % 8, whatever segment it belongs to;
-//  * a slab's operand tile (16 rows x C 16-byte chunks per row; C = 4 / 6 / 8 for fp4 / fp6 / fp8) is loaded as chunk e = 64 k + lane
-//    of the tile, row e / C, by instruction k: 4 / 6 / 8 consecutive lanes cover a row's contiguous bytes.  The scale bytes of the
-//    slab's 32 rows are one 8-byte load per lane over the 512-byte atom, handed to the lanes that need them by ds_bpermute;
-//  * the tiles go global -> LDS directly (buffer_load_dwordx4 ... lds, inline asm: no staging registers, no ds_write), into the
-//    wave's PRIVATE ring of D slots; every wave keeps D slabs in flight, issued and consumed in slab order in whole rounds of D
-//    steps with the same number of vector-memory instructions per step, so a counted s_waitcnt vmcnt((D - 1) * L) before a step
-//    leaves exactly the D - 1 younger slabs outstanding (a wave with cnt slabs starts with (D - cnt % D) % D phantom steps that
-//    re-request its first slab and skip the arithmetic).  No barrier: LDS-DMA completion is what vmcnt counts;
+// 11.5 us at M = 16.  Ablations on a register-ring version of it (profiles/r04_stream_ablation.txt) showed that the time was the sum
+// of its vector-memory instructions, at 30-45 cycles each whatever they fetched -- weights 2.8 us, activations 3.3 us, the three scale
+// dwords per slab 2.7 us -- and of its instruction stream, not a chain of round trips.  So here EVERY load is lane-contiguous and the
+// MFMA's (lane = row) operand layout is made in LDS:
+//  * one workgroup = 16 F output features x all tokens (T16 tiles of 16), its NW waves split K: the 128-deep slabs of N | S | O are
+//    numbered through (j = 0 .. T-1) and slab j goes to wave j % NW, whatever segment it belongs to;
+//  * a slab's operand tile (16 rows x C 16-byte chunks per row; C = 4 / 6 / 8 for fp4 / fp6 / fp8) goes global -> LDS directly
+//    (buffer_load_dwordx4 ... lds, inline asm: no staging registers, no ds_write) into the wave's PRIVATE ring of D slots.  A DMA
+//    instruction writes its 64 x 16 bytes to LDS in lane order, so WHICH chunk a lane fetches decides the LDS image: lane p = C q + c
+//    of a piece fetches chunk c ^ s(row) of row q (s = row >> 2 for 4 chunks per row, (row >> 1) & 7 for 8; fp6 tiles stay row-major):
+//    four / eight consecutive lanes cover one row's contiguous bytes, and the 16 lanes of a ds_read_b128 phase (16 rows, same chunk)
+//    hit 16 different bank groups.  The scale bytes of the slab's rows are one 8-byte load per lane over each 512-byte atom, handed to
+//    the lanes that need them by ds_bpermute (as one dword per lane at a stride of 8 bytes the same 512 bytes cost the launch 2 us),
+//    issued before the tiles (they come from L2 and would otherwise queue behind the weights);
+//  * every wave keeps D slabs in flight, issued and consumed in slab order in whole rounds of D steps with the same number L of
+//    vector-memory instructions per step, so a counted s_waitcnt vmcnt((D - 1) L) before a step leaves exactly the D - 1 younger
+//    slabs outstanding (a wave with cnt slabs starts with (D - cnt % D) % D phantom steps that re-request its first slab and skip the
+//    arithmetic).  No barrier in the loop: LDS-DMA completion is what vmcnt counts.  More waves with a shallow ring (8 x 2) beat
+//    fewer with a deep one; the same tiles through a register ring + ds_write measured the same;
 //  * instruction count is the currency: a wave64 VALU instruction holds its SIMD for 4 cycles, a 5 us launch leaves a wave a few
 //    hundred of them.  Everything that depends only on (segment, lane) -- descriptors, byte offsets, LDS addresses -- is computed
-//    once; a step selects by segment with three typed code paths (wave-uniform branches with the same loads in each, so the wait
-//    counts stay exact); workgroups have NW = 4 waves walking 8 slabs each at K = 4096 rather than 8 walking 4;
-//  * a DMA instruction writes its 64 x 16 bytes to LDS in lane order, so WHICH chunk a lane fetches decides the LDS image: lane
-//    p = C' q + c' of a piece fetches chunk c' ^ s(row) of row q (s = row >> 2 for 4 chunks per row, (row >> 1) & 7 for 8): four /
-//    eight consecutive lanes still cover one row's contiguous bytes, and the 16 lanes of a ds_read_b128 phase (16 rows, same chunk)
-//    hit 16 different bank groups.  Consuming a slab = reading the MFMA fragments (lane (row l & 15, K block l >> 4)) and
-//    v_mfma_scale_f32_16x16x128_f8f6f4 with the tokens on the rows; the fragment reads and the MFMA (operand formats are
-//    immediates) sit in a three-way wave-uniform branch; each segment has its own accumulators (a 16 x 16 fp32 tile is 4 registers);
-//  * ONE barrier: every wave leaves its partial sums of all segments in LDS, then thread o sums the eight partials of output o
-//    segment by segment and applies the reference's rounding chain on the reduced values.
+//    once; a step selects by segment with three typed code paths; the accumulators live in asm-owned AGPRs (through the builtin hipcc
+//    copied the three accumulator sets at the joins of the segment branch);
+//  * consuming a slab = reading the MFMA fragments (lane (row l & 15, K block l >> 4)) and v_mfma_scale_f32_16x16x128_f8f6f4 with the
+//    tokens on the rows; each segment has its own accumulators (a 16 x 16 fp32 tile is 4 registers);
+//  * ONE barrier (eight tiles per wave: one per segment): every wave leaves its partial sums in LDS, then thread o sums the partials of
+//    output o segment by segment and applies the reference's rounding chain on the reduced values.
 #include <stdio.h>
 #include <stdlib.h>
 
