@@ -13,7 +13,9 @@ struct QuantIn {
     int K[3];
     int M;
     int stage_rows;         // activation rows staged in LDS at a time (launcher: as many as fit)
+    int early;              // quantize_rows_early applies: one batch (stage_rows >= M), at most one group per thread, at most EARLY_RL row loads per thread
 };
+constexpr int EARLY_RL = 4;
 
 // LDS map: [staged bf16 rows | opN | opS | opO | scale bytes]; row r of a segment at op + r * pitch, its scale bytes at
 // scales + r * Gt + (first group of the segment)
@@ -77,6 +79,78 @@ __device__ __forceinline__ LdsMap quantize_rows_to_lds(const QuantIn &a, uint8_t
         __syncthreads();
     }
 
+    LdsMap m;
+    m.opN = opN; m.opS = opS; m.opO = opO; m.scales = scales;
+    m.pN = pN; m.pS = pS; m.pO = pO; m.Gt = Gt; m.gN = gN; m.gS = gS;
+    return m;
+}
+
+// The same phase with ALL of its global loads issued through inline asm before the caller's own untracked loads (`request()`: the
+// first slabs of mx_gemm_stream.hip's DMA ring, AFTER_LOADS vector-memory instructions when it returns true), and ONE counted wait:
+// the rows and indices are older than the ring, so vmcnt(AFTER_LOADS) certifies them while the weights stay in flight -- they are
+// requested ~1 us earlier than from the hook of quantize_rows_to_lds, which has to wait for the staged rows first.
+// Preconditions (QuantIn::early, set by the launcher): stage_rows >= M, M * K / 32 <= NT, M * K / 8 <= NT * EARLY_RL.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MM_DQ_DEVICE_ONLY(...) __VA_ARGS__
+#else
+#define MM_DQ_DEVICE_ONLY(...)
+#endif
+typedef unsigned dq_v4u __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ dq_v4u gload16(const void *p) {
+    dq_v4u d = {0u, 0u, 0u, 0u};
+    MM_DQ_DEVICE_ONLY(asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(d) : "v"(p) : "memory");)
+    return d;
+}
+template <int NT, int AFTER_LOADS, class Request>
+__device__ __forceinline__ LdsMap quantize_rows_early(const QuantIn &a, uint8_t *smem, Request request) {
+    const int Kt = a.K[0] + a.K[1] + a.K[2], Gt = Kt >> 5;
+    const int gN = a.K[0] >> 5, gS = a.K[1] >> 5;
+    const int pN = a.K[0] >> 1, pS = (a.K[1] >> 2) * 3, pO = a.K[2];
+    uint8_t *stage = smem;
+    uint8_t *opN = stage + (size_t)a.stage_rows * Kt * 2, *opS = opN + a.M * pN, *opO = opS + a.M * pS;
+    uint8_t *scales = opO + a.M * pO;
+    const int t = threadIdx.x, groups = a.M * Gt, chunks = a.M * (Kt >> 3);
+    const int rr = t < groups ? t / Gt : 0, g = t < groups ? t - rr * Gt : 0;
+    const uint4 *ip = reinterpret_cast<const uint4 *>(a.idx + (size_t)g * 32);
+    const uint4 *grow = reinterpret_cast<const uint4 *>(a.X);
+    dq_v4u iq[4], rq[EARLY_RL];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) iq[i] = gload16(ip + i);
+#pragma unroll
+    for (int k = 0; k < EARLY_RL; ++k) {
+        const int c = t + k * NT;
+        rq[k] = gload16(grow + (c < chunks ? c : chunks - 1));       // (past the end: the last chunk again, not stored)
+    }
+    const bool requested = request();
+    if (requested) { MM_DQ_DEVICE_ONLY(asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AFTER_LOADS) : "memory");) }
+    else { MM_DQ_DEVICE_ONLY(asm volatile("s_waitcnt vmcnt(0)" ::: "memory");) }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { MM_DQ_DEVICE_ONLY(asm volatile("" : "+v"(iq[i]));) }
+#pragma unroll
+    for (int k = 0; k < EARLY_RL; ++k) { MM_DQ_DEVICE_ONLY(asm volatile("" : "+v"(rq[k]));) }
+#pragma unroll
+    for (int k = 0; k < EARLY_RL; ++k) {
+        const int c = t + k * NT;
+        if (c < chunks) reinterpret_cast<dq_v4u *>(stage)[c] = rq[k];
+    }
+    __syncthreads();
+    if (t < groups) {
+        uint32_t ix[16];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ix[4 * i] = (iq[i][0] << 1) & 0xFFFEFFFEu;      // byte offsets into the staged row, two per register
+            ix[4 * i + 1] = (iq[i][1] << 1) & 0xFFFEFFFEu;
+            ix[4 * i + 2] = (iq[i][2] << 1) & 0xFFFEFFFEu;
+            ix[4 * i + 3] = (iq[i][3] << 1) & 0xFFFEFFFEu;
+        }
+        const uint8_t *row = stage + (size_t)rr * Kt * 2;
+        uint32_t byte;
+        if (g < gN) byte = quantize_group<EL_FP4>(row, ix, opN + rr * pN + g * 16);
+        else if (g < gN + gS) byte = quantize_group<EL_FP6>(row, ix, opS + rr * pS + (g - gN) * 24);
+        else byte = quantize_group<EL_FP8>(row, ix, opO + rr * pO + (g - gN - gS) * 32);
+        scales[rr * Gt + g] = (uint8_t)byte;
+    }
+    __syncthreads();
     LdsMap m;
     m.opN = opN; m.opS = opS; m.opO = opO; m.scales = scales;
     m.pN = pN; m.pS = pS; m.pO = pO; m.Gt = Gt; m.gN = gN; m.gS = gS;

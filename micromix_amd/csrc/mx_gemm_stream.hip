@@ -348,9 +348,11 @@ __device__ __forceinline__ void stream_body(const GemmArgs &a, const dq::QuantIn
 #pragma unroll
             for (int d = 0; d < D; ++d) issue(q[d], d, slab_of(d));
         }
+        return cnt > 0;
     };
     if constexpr (QUANT) {
-        L = dq::quantize_rows_to_lds<NT>(qi, smem_all, prime);
+        if (qi.early) L = dq::quantize_rows_early<NT, D * RG::LOADS>(qi, smem_all, prime);
+        else L = dq::quantize_rows_to_lds<NT>(qi, smem_all, [&]() { prime(); });
         const int rr = li < a.M ? li : 0;
         qx[0] = L.opN + rr * L.pN + 16 * h;
         qx[1] = L.opS + rr * L.pS + 24 * h;
@@ -520,6 +522,9 @@ static hipError_t launch_quant(const GemmArgs &a, dq::QuantIn qi, hipStream_t st
     }
     if (rows < 1) return hipErrorInvalidValue;
     qi.stage_rows = (int)rows;
+    qi.early = (rows >= (size_t)a.M && (size_t)a.M * (Kt / 32) <= 64u * NW && (size_t)a.M * (Kt / 8) <= 64u * NW * dq::EARLY_RL) ? 1 : 0;
+    static const int early_on = getenv("MICROMIX_DECODE_EARLY") ? atoi(getenv("MICROMIX_DECODE_EARLY")) : 1;   // kernel-developer override
+    if (!early_on) qi.early = 0;
     const size_t qbytes = rows * Kt * 2 + ops, lds = qbytes + tail;
     static DynamicLdsOnce once;
     if (lds > 65536) {
