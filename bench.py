@@ -657,8 +657,43 @@ def main():
                                       "weight_stream_TBps": round(wb_ / t_s / 1e12, 3),
                                       "kernel": lib.mm_matmul_describe(m_, nn_, *sp, 1, 4 if wsb else 0, wsb).decode()[:90]}
             del bs_
-        sm["note"] = "back-to-back direct C-ABI launches (mm_matmul_ws with the stream's split-K workspace where the plan wants one)"
+        sm["note"] = ("back-to-back direct C-ABI launches (mm_matmul_ws with the stream's split-K workspace where the plan wants one); the SAME "
+                      "weights every launch, i.e. served by the 256 MiB Infinity Cache -- `small_m_hbm` rotates through 12 weight sets")
         result["small_m"] = sm
+        # ---- the same launches with the weights coming from HBM: 12 different gate_proj-sized weight sets in rotation (12 x 31 MB > the
+        #      256 MiB Infinity Cache), as consecutive layers of a model would present them ----
+        hb = {}
+        nn_, kk_, sp = 14336, K, fsplit
+        sets = []
+        for r_ in range(12):
+            wr = (torch.randn((nn_, kk_), device=dev, dtype=torch.float32) * 0.02).to(torch.bfloat16)
+            sets.append(mixedgemm.reorder_quantize_w4(wr, idx, *sp))
+            del wr
+        xh = torch.randn((16, kk_), device=dev, dtype=torch.float32).to(torch.bfloat16)
+        oh = torch.empty((16, nn_), dtype=torch.bfloat16, device=dev)
+        wb_ = nn_ * kk_ // 2 + nn_ * kk_ // 32
+        for m_ in (1, 16):
+            ah = mixedgemm.reorder_quantize_x(xh[:m_].contiguous(), idx, *sp)
+            calls = []
+            for bs_ in sets:
+                pa = [t.data_ptr() if t.numel() else None for t in (ah[0], bs_[0], ah[1], bs_[1], ah[2], bs_[2], ah[3], bs_[3], ah[4], bs_[4], ah[5], bs_[5])]
+                calls.append(pa)
+            def frot(n_=12):
+                for pa in calls[:n_]:
+                    lib.mm_matmul(*pa, m_, nn_, *sp, 1, 0, None, oh.data_ptr(), stream_ptr)
+            settle(frot, 0.15)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                frot()
+            torch.cuda.synchronize()
+            t_r = (time.perf_counter() - t0) / (20 * 12)
+            hb[f"gate_up_M{m_}"] = {"M": m_, "N": nn_, "K": kk_, "split": list(sp), "us_per_launch": round(t_r * 1e6, 2),
+                                    "weight_stream_TBps": round(wb_ / t_r / 1e12, 3), "weight_sets": 12,
+                                    "kernel": lib.mm_matmul_describe(m_, nn_, *sp, 1, 0, 0).decode()[:90]}
+        hb["note"] = "mm_matmul on 12 weight sets in rotation (374 MB of packed weights: every launch streams its 31 MB from HBM); against 8 TB/s"
+        result["small_m_hbm"] = hb
+        del sets
         del bf
         result["few_tiles"] = few
 

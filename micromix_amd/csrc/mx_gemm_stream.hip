@@ -125,17 +125,22 @@ template <> struct Frag<2> { typedef v8i type; static constexpr int HW = HW_FP8;
 #define MM_STREAM_ACC48 MM_STREAM_ACC24,"a24","a25","a26","a27","a28","a29","a30","a31","a32","a33","a34","a35","a36","a37","a38","a39","a40","a41","a42","a43","a44","a45","a46","a47"
 #define MM_STREAM_ACC96 MM_STREAM_ACC48,"a48","a49","a50","a51","a52","a53","a54","a55","a56","a57","a58","a59","a60","a61","a62","a63","a64","a65","a66","a67","a68","a69","a70","a71", \
                         "a72","a73","a74","a75","a76","a77","a78","a79","a80","a81","a82","a83","a84","a85","a86","a87","a88","a89","a90","a91","a92","a93","a94","a95"
+#define MM_STREAM_ACC192 MM_STREAM_ACC96,"a96","a97","a98","a99","a100","a101","a102","a103","a104","a105","a106","a107","a108","a109","a110","a111","a112","a113","a114","a115","a116","a117","a118","a119", \
+                         "a120","a121","a122","a123","a124","a125","a126","a127","a128","a129","a130","a131","a132","a133","a134","a135","a136","a137","a138","a139","a140","a141","a142","a143", \
+                         "a144","a145","a146","a147","a148","a149","a150","a151","a152","a153","a154","a155","a156","a157","a158","a159","a160","a161","a162","a163","a164","a165","a166","a167", \
+                         "a168","a169","a170","a171","a172","a173","a174","a175","a176","a177","a178","a179","a180","a181","a182","a183","a184","a185","a186","a187","a188","a189","a190","a191"
 // (NACC = 12 F T16 accumulator registers: the clobber list names exactly those, the rest of the register file stays the compiler's)
 #define MM_STREAM_ASM_ACC(NACC, ...)                                                  \
     do {                                                                              \
         if constexpr ((NACC) <= 12) { MM_DEVICE_ONLY(asm volatile(__VA_ARGS__ : MM_STREAM_ACC12);) }       \
         else if constexpr ((NACC) <= 24) { MM_DEVICE_ONLY(asm volatile(__VA_ARGS__ : MM_STREAM_ACC24);) }  \
         else if constexpr ((NACC) <= 48) { MM_DEVICE_ONLY(asm volatile(__VA_ARGS__ : MM_STREAM_ACC48);) }  \
-        else { MM_DEVICE_ONLY(asm volatile(__VA_ARGS__ : MM_STREAM_ACC96);) }                              \
+        else if constexpr ((NACC) <= 96) { MM_DEVICE_ONLY(asm volatile(__VA_ARGS__ : MM_STREAM_ACC96);) }  \
+        else { MM_DEVICE_ONLY(asm volatile(__VA_ARGS__ : MM_STREAM_ACC192);) }                             \
     } while (0)
 template <int XEL, int WEL, int TILE, int NACC>
 __device__ __forceinline__ void mfma16(const typename Frag<XEL>::type &x, const typename Frag<WEL>::type &w, int sx, int sw) {
-    static_assert(4 * TILE + 3 < NACC && NACC <= 96, "a[0:95]");
+    static_assert(4 * TILE + 3 < NACC && NACC <= 192, "a[0:191]");
     MM_STREAM_ASM_ACC(NACC, "s_nop 1\n\tv_mfma_scale_f32_16x16x128_f8f6f4 a[%c6:%c7], %0, %1, a[%c6:%c7], %2, %3 op_sel_hi:[0,0,0] cbsz:%c4 blgp:%c5"
                       :
                       : "v"(x), "v"(w), "v"(sx), "v"(sw), "i"(Frag<XEL>::HW), "i"(Frag<WEL>::HW), "i"(4 * TILE), "i"(4 * TILE + 3));
@@ -246,7 +251,7 @@ __device__ __forceinline__ void stream_body(const GemmArgs &a, const dq::QuantIn
     const int rd4 = (4 * li + (h ^ (li >> 2))) * 16, rd6 = li * 96 + 24 * h;
     const int rd8a = (li >> 3) * 1024 + (8 * (li & 7) + (h ^ s8)) * 16, rd8b = (li >> 3) * 1024 + (8 * (li & 7) + ((4 + h) ^ s8)) * 16;
 
-    static_assert(12 * ACC <= 96, "a[0:95]");
+    static_assert(12 * ACC <= 192, "a[0:191]");
     static_for<12 * ACC>([&](auto r_) { acc_zero<decltype(r_)::value, 12 * ACC>(); });
 
     // slab s of segment G into slot d: RG::LOADS vector-memory instructions, whatever the segment
@@ -607,9 +612,9 @@ hipError_t launch_mx_gemm_stream(const GemmArgs &a, bool w4, hipStream_t stream)
     if (have) {
 #define MM_TRY(F_, D_, NW_)                                                                              \
     if (cf == F_ && cd == D_ && cn == NW_) return a.M <= 16 ? MM_STREAM(F_, 1, D_, NW_) : (a.M <= 32 ? MM_STREAM(F_, 2, D_, NW_) : MM_STREAM(F_, 4, D_, NW_));
-        if (cf == 4 && cd == 4 && cn == 4 && a.M <= 16) return MM_STREAM(4, 1, 4, 4);
-        if (cf == 4 && cd == 3 && cn == 8 && a.M <= 16) return MM_STREAM(4, 1, 3, 8);
-        if (cf == 4 && cd == 4 && cn == 8 && a.M <= 16) return MM_STREAM(4, 1, 4, 8);
+        if (cf == 4 && cd == 2 && cn == 4) return a.M <= 16 ? MM_STREAM(4, 1, 2, 4) : (a.M <= 32 ? MM_STREAM(4, 2, 2, 4) : MM_STREAM(4, 4, 2, 4));
+        if (cf == 4 && cd == 2 && cn == 8) return a.M <= 16 ? MM_STREAM(4, 1, 2, 8) : (a.M <= 32 ? MM_STREAM(4, 2, 2, 8) : hipErrorInvalidValue);
+        if (cf == 4 && cd == 3 && cn == 4) return a.M <= 16 ? MM_STREAM(4, 1, 3, 4) : (a.M <= 32 ? MM_STREAM(4, 2, 3, 4) : hipErrorInvalidValue);
         MM_TRY(1, 4, 4) MM_TRY(1, 6, 4) MM_TRY(1, 4, 8) MM_TRY(1, 2, 8) MM_TRY(1, 3, 8) MM_TRY(1, 2, 16)
         MM_TRY(2, 3, 4) MM_TRY(2, 4, 4) MM_TRY(2, 4, 8) MM_TRY(2, 3, 8) MM_TRY(2, 2, 8) MM_TRY(2, 2, 16) MM_TRY(2, 1, 16)
 #undef MM_TRY
