@@ -41,7 +41,7 @@ if plain:
     lines.append(f"== bench.py JSON line of an unprofiled run of the same command on the same box ({CMD}) ==")
     lines.append(plain[-1].strip())
 traffic = None
-SMALL = ("few", "kv", "decode", "gateup")     # launches that are not ONE round of 256 eight-wave workgroups: ratios only
+SMALL = ("few", "kv", "decode", "stream", "gateup")     # launches that are not ONE round of 256 eight-wave workgroups: ratios only
 for name in ("fp8", "fp4", "mixed", "mixed3072", "down") + SMALL:   # (gateup: 1792 workgroups of the fused gate / up kernel)
     d = os.path.join(root, "gpurun_out", f"pmc_{tag}_{name}")
     agg = collections.defaultdict(list)
