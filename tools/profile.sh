@@ -24,3 +24,5 @@ for cfg in "fp8 0,0,4096" "fp4 4096,0,0" "mixed 2048,128,1920" "mixed3072 3072,8
   bash tools/pmc_gemm.sh ${TAG}_$1 $2 > /dev/null 2>&1
 done
 python3 tools/profile_summary.py $OUT $TAG
+# the summaries are now under gpurun_out/profiles_$TAG/ (merged back by gpurun): copy them into profiles/; delete $OUT and
+# gpurun_out/pmc_${TAG}_* on the box first if the raw traces would push gpurun_out/ past its 64 MiB merge limit

@@ -36,7 +36,10 @@ for name, N, K, split in (("q/o", 4096, 4096, (2048, 128, 1920)), ("k/v", 1024, 
         a = mixedgemm.reorder_quantize_x(x, idx, *split)
         out = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
         ptrs = [pp(t) for t in (a[0], b[0], a[1], b[1], a[2], b[2], a[3], b[3], a[4], b[4], a[5], b[5])]
-        f = lambda: lib.mm_matmul(*ptrs, M, N, *split, 1, 0, None, out.data_ptr(), st)
+        wsb = lib.mm_matmul_workspace_bytes(M, N, *split, 1, 4)        # the stream's split-K workspace where the plan wants one (tickets zeroed)
+        ws = mixedgemm.split_workspace(dev, wsb) if wsb else None
+        f = (lambda: lib.mm_matmul_ws(*ptrs, M, N, *split, 1, 4, None, out.data_ptr(), ws.data_ptr(), ws.numel(), st)) if ws is not None else \
+            (lambda: lib.mm_matmul(*ptrs, M, N, *split, 1, 0, None, out.data_ptr(), st))
         assert f() == 0
         us = timed(f)
         row.append(f"M={M}: {us:6.2f} us {wbytes / us / 1e6:4.2f} TB/s")
