@@ -374,7 +374,10 @@ int mm_matmul_grouped(const mm_group *groups, int ngroups, int N, int KN, int KS
     auto flush_small = [&]() -> int {
         if (nsmall == 0) return MM_OK;
         small.ngroups = nsmall;
-        hipError_t e = mm::launch_mx_gemm_skinny_grouped(small, max_m, wmode == MM_W_FP4, (hipStream_t)stream);
+        const int Ks[3] = {KN, KS, KO};
+        hipError_t e = mm::mx_gemm_stream_grouped_supported(max_m, nsmall, N, Ks)
+                           ? mm::launch_mx_gemm_stream_grouped(small, max_m, wmode == MM_W_FP4, (hipStream_t)stream)
+                           : mm::launch_mx_gemm_skinny_grouped(small, max_m, wmode == MM_W_FP4, (hipStream_t)stream);
         nsmall = 0;
         max_m = 0;
         return e == hipSuccess ? MM_OK : fail_hip(e, "mm_matmul_grouped");

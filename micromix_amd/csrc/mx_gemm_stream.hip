@@ -504,6 +504,31 @@ static hipError_t launch_one(const GemmArgs &a, hipStream_t stream) {
     return hipGetLastError();
 }
 
+// Grouped launch (MoE experts): blockIdx.y picks one of up to MM_MAX_GROUPS problems that share N, the K split and the weight mode
+// (as mx_gemm_skinny_grouped_kernel); T16 covers the largest group, a group with M = 0 returns at once.
+template <int F, int T16, int D, int NW, bool W4>
+__global__ void __launch_bounds__(64 * NW) mx_gemm_stream_grouped_kernel(GroupedGemmArgs ga) {
+    const GemmArgs &a = ga.g[blockIdx.y];
+    if (a.M > 0) stream_body<F, T16, D, NW, W4>(a);
+}
+
+template <int F, int T16, int D, int NW, bool W4>
+static hipError_t launch_grouped_one(const GroupedGemmArgs &ga, hipStream_t stream) {
+    const GemmArgs &a = ga.g[0];
+    const int present = (a.K[0] ? 1 : 0) + (a.K[1] ? 1 : 0) + (a.K[2] ? 1 : 0);
+    const int red_bytes = NW * (F * T16 >= 8 ? 1 : present) * F * T16 * 4 * 64 * (int)sizeof(float), stage_bytes = NW * D * Ring<F, T16, W4>::SLOT;
+    const int lds = red_bytes > stage_bytes ? red_bytes : stage_bytes;
+    static DynamicLdsOnce once;
+    if (lds > 65536) {
+        constexpr int MAX_RED = NW * (F * T16 >= 8 ? 1 : 3) * F * T16 * 1024, MAX_STAGE = NW * D * Ring<F, T16, W4>::SLOT;
+        hipError_t e = once.ensure(reinterpret_cast<const void *>(mx_gemm_stream_grouped_kernel<F, T16, D, NW, W4>), MAX_RED > MAX_STAGE ? MAX_RED : MAX_STAGE);
+        if (e != hipSuccess) return e;
+    }
+    const int blocks = (a.N + 16 * F - 1) / (16 * F);
+    hipLaunchKernelGGL((mx_gemm_stream_grouped_kernel<F, T16, D, NW, W4>), dim3(blocks, ga.ngroups), dim3(64 * NW), lds, stream, ga);
+    return hipGetLastError();
+}
+
 // mm_qlinear_decode on the streaming kernel: the workgroup quantizes the M <= 8 rows itself (QUANT)
 template <int F, int D, int NW, bool W4>
 __global__ void __launch_bounds__(64 * NW) mx_qlinear_stream_kernel(GemmArgs a, dq::QuantIn qi, int qbytes) {
@@ -548,6 +573,23 @@ extern "C" int mm_diag_set_stream_clock(void *buf) {
     return hipMemcpyToSymbol(HIP_SYMBOL(stream::g_stream_clock), &buf, sizeof(buf)) == hipSuccess ? 0 : 3;
 }
 #endif
+
+// the grouped launch on the streaming kernel: every group M <= 32 (one or two token tiles); the workgroups of all groups count towards
+// filling the CUs
+bool mx_gemm_stream_grouped_supported(int max_m, int ngroups, int N, const int K[3]) {
+    static const int on = getenv("MICROMIX_STREAM_GROUPED") ? atoi(getenv("MICROMIX_STREAM_GROUPED")) : 1;   // kernel-developer override
+    (void)N; (void)K;
+    return on && max_m >= 1 && max_m <= 32 && ngroups >= 1 && ngroups <= MM_MAX_GROUPS;
+}
+hipError_t launch_mx_gemm_stream_grouped(const GroupedGemmArgs &ga, int max_m, bool w4, hipStream_t stream) {
+    using namespace stream;
+    const bool wide = (ga.g[0].N + 31) / 32 * ga.ngroups >= device_cus();
+#define MM_STREAM_G(F_, T_, D_, NW_)                                                 \
+    (w4 ? launch_grouped_one<F_, T_, D_, NW_, true>(ga, stream) : launch_grouped_one<F_, T_, D_, NW_, false>(ga, stream))
+    if (max_m <= 16) return wide ? MM_STREAM_G(2, 1, 2, 8) : MM_STREAM_G(1, 1, 3, 8);
+    return wide ? MM_STREAM_G(2, 2, 3, 4) : MM_STREAM_G(1, 2, 3, 8);
+#undef MM_STREAM_G
+}
 
 bool mx_gemm_stream_supported(int M, int N, const int K[3], bool w4) {
     static const int on = getenv("MICROMIX_STREAM") ? atoi(getenv("MICROMIX_STREAM")) : 1;   // kernel-developer override
