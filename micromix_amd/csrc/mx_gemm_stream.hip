@@ -574,12 +574,13 @@ extern "C" int mm_diag_set_stream_clock(void *buf) {
 }
 #endif
 
-// the grouped launch on the streaming kernel: every group M <= 32 (one or two token tiles); the workgroups of all groups count towards
+// the grouped launch on the streaming kernel: every group M <= 64 (one to four token tiles); the workgroups of all groups count towards
 // filling the CUs
 bool mx_gemm_stream_grouped_supported(int max_m, int ngroups, int N, const int K[3]) {
     static const int on = getenv("MICROMIX_STREAM_GROUPED") ? atoi(getenv("MICROMIX_STREAM_GROUPED")) : 1;   // kernel-developer override
     (void)N; (void)K;
-    return on && max_m >= 1 && max_m <= 32 && ngroups >= 1 && ngroups <= MM_MAX_GROUPS;
+    static const int max_tokens = getenv("MICROMIX_STREAM_GROUPED_MAX_M") ? atoi(getenv("MICROMIX_STREAM_GROUPED_MAX_M")) : 64;
+    return on && max_m >= 1 && max_m <= max_tokens && max_m <= 64 && ngroups >= 1 && ngroups <= MM_MAX_GROUPS;
 }
 hipError_t launch_mx_gemm_stream_grouped(const GroupedGemmArgs &ga, int max_m, bool w4, hipStream_t stream) {
     using namespace stream;
@@ -587,7 +588,9 @@ hipError_t launch_mx_gemm_stream_grouped(const GroupedGemmArgs &ga, int max_m, b
 #define MM_STREAM_G(F_, T_, D_, NW_)                                                 \
     (w4 ? launch_grouped_one<F_, T_, D_, NW_, true>(ga, stream) : launch_grouped_one<F_, T_, D_, NW_, false>(ga, stream))
     if (max_m <= 16) return wide ? MM_STREAM_G(2, 1, 2, 8) : MM_STREAM_G(1, 1, 3, 8);
-    return wide ? MM_STREAM_G(2, 2, 3, 4) : MM_STREAM_G(1, 2, 3, 8);
+    if (max_m <= 32) return wide ? MM_STREAM_G(2, 2, 3, 4) : MM_STREAM_G(1, 2, 3, 8);
+    if (max_m <= 48) return wide ? MM_STREAM_G(2, 3, 2, 4) : MM_STREAM_G(1, 3, 2, 8);
+    return wide ? MM_STREAM_G(2, 4, 2, 4) : MM_STREAM_G(1, 4, 2, 8);
 #undef MM_STREAM_G
 }
 

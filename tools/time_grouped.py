@@ -22,7 +22,7 @@ for name, N, K, split in (("w1/w3 (each)", 14336, 4096, (3584, 256, 256)), ("w2"
     idxs = [torch.randperm(K, generator=g).to(torch.int16).to(dev) for _ in range(E)]
     Bs = [mixedgemm.reorder_quantize_w4(w, i, *split) for w, i in zip(ws, idxs)]
     del ws
-    for ms in ((1,) * 8, (8,) * 8, (3, 0, 9, 1, 0, 20, 2, 5), (128,) * 8, (256,) * 8, (100, 300, 64, 200, 150, 90, 500, 120)):
+    for ms in ((1,) * 8, (8,) * 8, (3, 0, 9, 1, 0, 20, 2, 5), (40,) * 8, (64,) * 8, (30, 64, 1, 50, 12, 0, 33, 17), (128,) * 8, (256,) * 8, (100, 300, 64, 200, 150, 90, 500, 120)):
         As = [mixedgemm.reorder_quantize_x(torch.randn((m, K), generator=g).to(torch.bfloat16).to(dev), i, *split) for m, i in zip(ms, idxs)]
         outs = [torch.empty((m, N), dtype=torch.bfloat16, device=dev) for m in ms]
         arr = (_lib.MMGroup * E)()
@@ -37,4 +37,6 @@ for name, N, K, split in (("w1/w3 (each)", 14336, 4096, (3584, 256, 256)), ("w2"
                                   pp(a[5]), pp(b[5]), m, N, *split, 1, 0, None, o.data_ptr(), st)
         grouped = lambda: lib.mm_matmul_grouped(arr, E, N, *split, 1, 0, st)
         assert grouped() == 0
-        print(f"{name:13s} N={N} K={K} tokens per expert {ms}: per-expert loop {timed(loop):6.1f} us   grouped {timed(grouped):6.1f} us", flush=True)
+        t_loop, t_grouped = timed(loop), timed(grouped)
+        again = f"   (loop again {timed(loop):6.1f}, grouped again {timed(grouped):6.1f})" if os.environ.get("TIME_GROUPED_TWICE") else ""
+        print(f"{name:13s} N={N} K={K} tokens per expert {ms}: per-expert loop {t_loop:6.1f} us   grouped {t_grouped:6.1f} us{again}", flush=True)
