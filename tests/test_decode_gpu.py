@@ -13,7 +13,11 @@ pytestmark = pytest.mark.gpu
 CASES = [(1, 128, 128, (128, 0, 0)), (1, 256, 4096, (0, 0, 4096)), (3, 200, 1024, (512, 128, 384)), (8, 384, 2048, (1024, 512, 512)),
          (2, 160, 5120, (4096, 512, 512)), (8, 128, 14336, (7168, 512, 6656)), (5, 96, 384, (0, 384, 0)), (7, 1024, 512, (256, 0, 256)),
          (2, 4128, 256, (128, 0, 128)), (8, 4200, 384, (128, 128, 128)),   # N > 4096: the 32-feature kernel (fewer than 16-feature workgroups per CU)
-         (3, 8230, 256, (128, 0, 128)), (1, 16400, 384, (128, 128, 128))]  # more feature blocks than CUs: one workgroup per CU walks them (ragged last block)
+         (3, 8230, 256, (128, 0, 128)), (1, 16400, 384, (128, 128, 128)),  # more feature blocks than CUs (ragged last block); M <= 4: the streaming kernel
+         # wide layers at M <= 4 run on mx_gemm_stream.hip with the quantization inside every workgroup: whole rounds of its ring, every
+         # format, the early-request path (all rows staged at once) and the hook path (M * K / 32 > 512 groups)
+         (2, 8200, 4096, (2048, 128, 1920)), (4, 8192, 1024, (512, 128, 384)), (1, 8448, 1152, (0, 0, 1152)), (4, 8320, 5120, (4096, 512, 512)),
+         (3, 8192, 2304, (0, 2304, 0))]
 
 
 @pytest.mark.parametrize("wmode", ("w4", "w"))
