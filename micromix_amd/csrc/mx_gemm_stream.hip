@@ -611,6 +611,7 @@ bool qlinear_stream_supported(int M, int N, const int K[3]) {
     // it wins where N / 32 fills the CUs and one pass quantizes the rows (gate/up at M = 1 / 2 / 4: 12.5 / 11.8 / 14.3 -> 10.2 / 9.2 /
     // 12.3 us) and loses on q/k/v/o (few workgroups: all start-up) and at M = 8 (two passes per workgroup: quantize + GEMM wins there).
     const size_t Kt = (size_t)K[0] + K[1] + K[2];
+    if (on == 2 && M >= 1 && M <= 8) return dq::operand_bytes(M, K) + Kt * 2 + 48 * 1024 + 64 <= 156 * 1024;     // (A/B runs: every shape that fits)
     if (!on || M < 1 || M > 4 || (N + 31) / 32 < device_cus()) return false;
     return dq::operand_bytes(M, K) + Kt * 2 + 48 * 1024 + 64 <= 156 * 1024;
 }
