@@ -69,3 +69,11 @@ def test_the_guard_itself_detects_a_violation():
             ".end_amdhsa_kernel\n")
     bad = check_acc_regs.check(fake)
     assert [c.split()[0] for _, c in bad] == ["ds_read2st64_b64", "v_accvgpr_read_b32"]
+
+
+def test_every_csrc_header_is_a_build_dependency():
+    """a header missing from micromix_amd.build.HEADERS would not trigger a rebuild when it changes (mx_decode_quant.h in round 4)"""
+    from micromix_amd import build
+    listed = {os.path.basename(h) for h in build.HEADERS}
+    present = {f for f in os.listdir(build.CSRC) if f.endswith((".h", ".inc"))}
+    assert present <= listed, sorted(present - listed)
