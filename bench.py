@@ -626,7 +626,7 @@ def main():
         gbytes = ng * K // 2 + ng * K // 32
         dec["gate_up_M1"] = {"M": 1, "N": ng, "K": K, "split": list(fsplit), "us_per_launch": round(t_g * 1e6, 2),
                              "weight_stream_TBps": round(gbytes / t_g / 1e12, 3),
-                             "note": "448 feature blocks walked by one workgroup per CU (the activation row is quantized once per workgroup)"}
+                             "note": "mm_qlinear_decode: quantize + GEMM in one launch; 448 workgroups of the weight-streaming kernel, each quantizes the row into LDS while its first weight slabs are in flight"}
         del bg
         result["decode"] = dec
         # ---- the largest GEMMs of a decoder layer at M = 16 / 32 / 64 (speculative / batched decode): weight bytes against 8 TB/s ----
