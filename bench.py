@@ -210,8 +210,11 @@ def llama_layer(dev, lib, mixedgemm, x, steps):
         else:
             mm(mixedgemm.reorder_quantize_x(xm, idx, *in_split), w_qkv)
             o = mm(mixedgemm.reorder_quantize_x(attn, idx, *in_split), w_o)
-        qm = mixedgemm.reorder_quantize_x(o, idx, *in_split)
-        qh = mixedgemm.gate_up_activate(qm, w_gu, *down_split)            # M <= 64: GEMM into scratch + the quantizer on it
+        if mixedgemm.qlinear_decode_supported(m, 2 * I, *in_split) == 2:
+            qh = mixedgemm.gate_up_activate_decode(o, idx, w_gu, *down_split)   # quantize + gate | up GEMM in one launch, then the quantizer
+        else:
+            qm = mixedgemm.reorder_quantize_x(o, idx, *in_split)
+            qh = mixedgemm.gate_up_activate(qm, w_gu, *down_split)        # M <= 64: GEMM into scratch + the quantizer on it
         return mm(qh, w_down)
 
     def measure(fn, xm, attn, reps):
@@ -259,7 +262,8 @@ def llama_layer(dev, lib, mixedgemm, x, steps):
         fn = prefill if m > 64 else decode
         ts, tg = measure(fn, xm, attn, max(5, steps if m > 64 else 4 * steps))
         fused_dec = m <= 64 and bool(mixedgemm.qlinear_decode_supported(m, H + 2 * NKV, *in_split))
-        ent = {"launches_per_layer": 7 if m > 64 else (6 if fused_dec else 8),
+        mlp_dec = m <= 64 and mixedgemm.qlinear_decode_supported(m, 2 * I, *in_split) == 2     # gate_up_activate_decode: one launch fewer
+        ent = {"launches_per_layer": 7 if m > 64 else ((6 if fused_dec else 8) - (1 if mlp_dec else 0)),
                "us_per_layer_stream": round(ts * 1e6, 1), "us_per_layer_graph": round(tg * 1e6, 1) if tg else None,
                "tokens_per_s_stream": round(m / ts, 1), "tokens_per_s_graph": round(m / tg, 1) if tg else None}
         # `tokens_per_s` by a FIXED rule, not the better of the two: prefill-sized batches (M > 64) are GPU-bound and run as stream

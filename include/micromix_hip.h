@@ -190,6 +190,14 @@ int mm_gate_up_activate(const uint8_t *AN, const uint8_t *BN, const uint8_t *AS,
                         const uint8_t *SFAO, const uint8_t *SFBO, int M, int I, int KN, int KS, int KO, int DN, int DS, int DO,
                         int flags, uint8_t *oN, uint8_t *oS, uint8_t *oO, uint8_t *sfN, uint8_t *sfS, uint8_t *sfO, void *workspace,
                         size_t workspace_bytes, mm_stream_t stream);
+/* The same for decode-sized batches, from the bf16 activations: reorder + quantize + gate | up GEMM in one launch (mm_qlinear_decode on the
+ * interleaved weight, M <= 8, mm_qlinear_decode_supported(M, 2 I, ...) != 0, else MM_ERR_UNSUPPORTED) into `workspace` (M * 2 I bf16
+ * values, 16-byte aligned), then silu(gate) * up + the MX quantization for down_proj: two launches instead of the three of
+ * mm_reorder_quantize -> mm_gate_up_activate, the same bytes.  flags as mm_gate_up_activate. */
+int mm_gate_up_activate_decode(const void *X_bf16, const int16_t *reorder_index, const uint8_t *BN, const uint8_t *BS, const uint8_t *BO,
+                               const uint8_t *SFBN, const uint8_t *SFBS, const uint8_t *SFBO, int M, int I, int KN, int KS, int KO, int DN,
+                               int DS, int DO, int flags, uint8_t *oN, uint8_t *oS, uint8_t *oO, uint8_t *sfN, uint8_t *sfS, uint8_t *sfO,
+                               void *workspace, size_t workspace_bytes, mm_stream_t stream);
 /* which kernels mm_gate_up_activate launches for (M, I) (thread-local buffer, as mm_matmul_describe) */
 const char *mm_gate_up_activate_describe(int M, int I);
 

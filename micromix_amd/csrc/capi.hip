@@ -274,6 +274,28 @@ int mm_gate_up_activate(const uint8_t *AN, const uint8_t *BN, const uint8_t *AS,
     return e == hipSuccess ? MM_OK : fail_hip(e, "mm_gate_up_activate");
 }
 
+int mm_gate_up_activate_decode(const void *X_bf16, const int16_t *reorder_index, const uint8_t *BN, const uint8_t *BS, const uint8_t *BO,
+                               const uint8_t *SFBN, const uint8_t *SFBS, const uint8_t *SFBO, int M, int I, int KN, int KS, int KO, int DN,
+                               int DS, int DO, int flags, uint8_t *oN, uint8_t *oS, uint8_t *oO, uint8_t *sfN, uint8_t *sfS, uint8_t *sfO,
+                               void *workspace, size_t workspace_bytes, mm_stream_t stream) {
+    if (M < 0 || I < 0 || KN < 0 || KS < 0 || KO < 0) return MM_ERR_BAD_ARG;
+    if ((KN % 128) || (KS % 128) || (KO % 128) || KN + KS + KO == 0) return MM_ERR_BAD_SPLIT;
+    if (!split_ok(DN + DS + DO, DN, DS, DO) || DN + DS + DO != I) return MM_ERR_BAD_SPLIT;
+    if (flags & ~MM_ROUND_ONCE) return MM_ERR_BAD_ARG;
+    if (M == 0) return MM_OK;
+    const int N = 2 * I;
+    if (!mm_qlinear_decode_supported(M, N, KN, KS, KO)) return MM_ERR_UNSUPPORTED;
+    if ((DN && (!oN || !sfN)) || (DS && (!oS || !sfS)) || (DO && (!oO || !sfO))) return MM_ERR_BAD_ARG;
+    if (!workspace || workspace_bytes < (size_t)M * N * sizeof(uint16_t) || ((uintptr_t)workspace & 15)) return MM_ERR_BAD_ARG;
+    // quantize + gate | up GEMM in one launch into the scratch (columns alternate 128 gate | 128 up), then the activation quantizer on
+    // that layout: the bytes of mm_reorder_quantize -> mm_gate_up_activate (tests/test_gate_up_gpu.py)
+    const int st = mm_qlinear_decode(X_bf16, reorder_index, BN, BS, BO, SFBN, SFBS, SFBO, M, N, KN, KS, KO, MM_W_FP4, flags, nullptr, workspace, stream);
+    if (st != MM_OK) return st;
+    hipError_t e = mm::launch_direct_quantize(workspace, (const uint16_t *)workspace + 128, M, DN, DS, DO, 3, oN, oS, oO, sfN, sfS, sfO,
+                                              (hipStream_t)stream);
+    return e == hipSuccess ? MM_OK : fail_hip(e, "mm_gate_up_activate_decode");
+}
+
 int mm_matmul_ws_reset(void *workspace, size_t workspace_bytes, mm_stream_t stream) {
     if (!workspace || workspace_bytes < MM_WS_TICKET_BYTES || ((uintptr_t)workspace & 15)) return MM_ERR_BAD_ARG;
     static_assert(MM_WS_TICKET_BYTES % 16 == 0 && MM_WS_TICKET_BYTES / 16 <= 1024, "one workgroup clears the ticket words");

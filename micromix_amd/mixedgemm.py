@@ -469,6 +469,52 @@ def qlinear_decode_supported(M, N, KN, KS, KO):
     return int(_lib.load().mm_qlinear_decode_supported(int(M), int(N), int(KN), int(KS), int(KO)))
 
 
+def gate_up_activate_decode(X, reorder_index, B, DN, DS, DO, *, rounding="reference"):
+    """`gate_up_activate(reorder_quantize_x(X, reorder_index, KN, KS, KO), B, DN, DS, DO)` for decode-sized batches in TWO launches
+    instead of three: reorder + quantize + the gate | up GEMM as one launch (`qlinear_decode` on the interleaved weight B), then
+    silu(gate) * up + the quantization for down_proj.  X [M, K] bf16 with M <= 8 and `qlinear_decode_supported(M, 2 I, KN, KS, KO)`;
+    (KN, KS, KO) are read off B.  Same bytes as the three-launch form.  Not an export of the reference module."""
+    lib = _lib.load()
+    dev = X.device
+    index = dev.index
+    if not (X.is_cuda and _ok(X, torch.bfloat16, index) and _ok(reorder_index, torch.int16, index)):
+        _check_tensor(X, "X", torch.bfloat16)
+        _check_tensor(reorder_index, "reorder_index", torch.int16, dev)
+    for t in B:
+        if not _ok(t, torch.uint8, index):
+            _check_tensor(t, "operand", torch.uint8, dev)
+    M, K = X.shape
+    N2 = B[0].size(0)
+    KN, KS, KO = B[0].size(1) * 2, B[1].size(1) * 2, B[2].size(1) * 2
+    I = N2 // 2
+    DN, DS, DO = int(DN), int(DS), int(DO)
+    if N2 % 256 or K != KN + KS + KO or reorder_index.numel() != K or B[1].size(0) != N2 or B[2].size(0) != N2:
+        raise RuntimeError("B must be an interleaved fp4 gate/up weight (interleave_gate_up) whose split adds up to X's columns")
+    if DN < 0 or DS < 0 or DO < 0 or DN % 128 or DS % 128 or DO % 128 or DN + DS + DO != I:
+        _lib.check(_lib.MM_ERR_BAD_SPLIT, "activate_quantize_x")
+    for n, t, need in (("SFBN", B[3], _sf_bytes_w(N2, KN)), ("SFBS", B[4], _sf_bytes_w(N2, KS)), ("SFBO", B[5], _sf_bytes_w(N2, KO))):
+        if t.numel() < need:
+            raise RuntimeError(f"{n} holds {t.numel()} scale bytes, needs at least {need}")
+    if rounding not in ("reference", "fused"):
+        raise ValueError("rounding must be 'reference' or 'fused'")
+    flags = _lib.MM_ROUND_PER_SEGMENT if rounding == "reference" else _lib.MM_ROUND_ONCE
+    u8 = torch.uint8
+    oN = torch.empty((M, DN // 2), dtype=u8, device=dev)
+    oS = torch.empty((M, DS // 4 * 3), dtype=u8, device=dev)
+    oO = torch.empty((M, DO), dtype=u8, device=dev)
+    sfN = torch.empty((_sf_bytes_x(M, DN),), dtype=u8, device=dev)
+    sfS = torch.empty((_sf_bytes_x(M, DS),), dtype=u8, device=dev)
+    sfO = torch.empty((_sf_bytes_x(M, DO),), dtype=u8, device=dev)
+    ws = torch.empty((M * N2 * 2,), dtype=u8, device=dev)      # stream-ordered scratch from the caching allocator
+    with _on_device(index):
+        st = lib.mm_gate_up_activate_decode(_ptr(X), _ptr(reorder_index), _ptr(B[0]), _ptr(B[1]), _ptr(B[2]), _ptr(B[3]), _ptr(B[4]), _ptr(B[5]),
+                                            M, I, KN, KS, KO, DN, DS, DO, flags, _ptr(oN), _ptr(oS), _ptr(oO), _ptr(sfN), _ptr(sfS), _ptr(sfO),
+                                            _ptr(ws), ws.numel(), _stream_ptr(dev))
+    if st:
+        _lib.check(st, "gate_up_activate_decode")
+    return oN, oS, oO, sfN, sfS, sfO
+
+
 def qlinear_decode(X, reorder_index, BN, BS, BO, SFBN, SFBS, SFBO, KN, KS, KO, *, bias=None, rounding="reference", out=None):
     """reorder_quantize_x + matmul (+ bias) of `QLinearLayer.forward` (qLinearLayer.py:58-74) as ONE launch for M <= 8 rows.
 

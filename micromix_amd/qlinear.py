@@ -240,7 +240,7 @@ class FusedQLinear(nn.Module):
 
 class FusedMLP(nn.Module):
     """gate_proj, up_proj, act_fn(gate) * up and down_proj of one decoder MLP (model/qLlamaLayer.py:336-387) in three launches
-    instead of the reference's five (quantize x once instead of twice; gate + up + silu * up + the quantization for down_proj as ONE
+    (M > 64; at most four below) instead of the reference's five (quantize x once instead of twice; gate + up + silu * up + the quantization for down_proj as ONE
     GEMM launch, `mixedgemm.gate_up_activate`; down_proj).  `gate` and `up` are QLinearLayers over the same input with the same
     reorder index and split (fp4 weights), whose output features are already in down_proj's reordered order -- the reference folds
     that order into gate / up (`out_reorder_index`, qLlamaLayer.py:341,354); `w_down` [H, I] has its columns in that order and
@@ -273,9 +273,13 @@ class FusedMLP(nn.Module):
     def forward(self, x):
         lead = x.shape[:-1]
         x2 = x.reshape(-1, self.hidden).contiguous()
-        qx = mixedgemm.reorder_quantize_x(x2, self.reorder_index, *self.in_split)
-        qh = mixedgemm.gate_up_activate(qx, (self.GU_BN, self.GU_BS, self.GU_BO, self.GU_SFBN, self.GU_SFBS, self.GU_SFBO),
-                                        *self.down_split, rounding=self.rounding)
+        gu = (self.GU_BN, self.GU_BS, self.GU_BO, self.GU_SFBN, self.GU_SFBS, self.GU_SFBO)
+        if x2.size(0) <= 8 and mixedgemm.qlinear_decode_supported(x2.size(0), 2 * self.inter, *self.in_split) == 2:
+            # decode: reorder + quantize + the gate | up GEMM in one launch, then the activation quantizer (same bytes, one launch fewer)
+            qh = mixedgemm.gate_up_activate_decode(x2, self.reorder_index, gu, *self.down_split, rounding=self.rounding)
+        else:
+            qx = mixedgemm.reorder_quantize_x(x2, self.reorder_index, *self.in_split)
+            qh = mixedgemm.gate_up_activate(qx, gu, *self.down_split, rounding=self.rounding)
         y = mixedgemm.matmul(qh[0], self.D_BN, qh[1], self.D_BS, qh[2], self.D_BO, qh[3], self.D_SFBN, qh[4], self.D_SFBS, qh[5],
                              self.D_SFBO, rounding=self.rounding)
         return y.reshape(*lead, self.hidden)

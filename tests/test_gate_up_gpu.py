@@ -76,6 +76,30 @@ def test_fused_equals_three_ops(dev, m, h, i, in_split, dsplit):
     assert ("act_kernel" in desc) == (m > 64), desc
 
 
+# the decode form (bf16 activations in, two launches): the same bytes as reorder_quantize_x -> gate_up_activate.  Small shapes (first
+# fused decode kernel), a wide layer at M <= 4 (the streaming kernel with the quantization inside every workgroup) and Llama's own MLP
+DECODE = [(1, 256, 256, (0, 0, 256), (128, 0, 128)), (3, 384, 512, (128, 128, 128), (256, 128, 128)), (8, 640, 1280, (256, 128, 256), (1024, 128, 128)),
+          (2, 1024, 4224, (512, 128, 384), (3072, 512, 640)), (1, 4096, 14336, (2048, 128, 1920), (12288, 1024, 1024))]
+
+
+@pytest.mark.parametrize("m,h,i,in_split,dsplit", DECODE, ids=[f"{c[0]}x{c[1]}x{c[2]}" for c in DECODE])
+def test_decode_form_equals_quantize_then_fused(dev, m, h, i, in_split, dsplit):
+    import torch
+    rng = np.random.default_rng(m * 7 + h + i)
+    x = t_from_bits(make_inputs(rng, m, h), dev)
+    wg = t_from_bits(make_inputs(rng, i, h, "weight"), dev) * 8
+    wu = t_from_bits(make_inputs(rng, i, h, "weight"), dev) * 8
+    idx = torch.from_numpy(rng.permutation(h).astype(np.int16)).to(dev)
+    qgu = mixedgemm.interleave_gate_up(mixedgemm.reorder_quantize_w4(wg, idx, *in_split), mixedgemm.reorder_quantize_w4(wu, idx, *in_split))
+    assert mixedgemm.qlinear_decode_supported(m, 2 * i, *in_split) >= 1
+    for rounding in ("reference", "fused"):
+        want = mixedgemm.gate_up_activate(mixedgemm.reorder_quantize_x(x, idx, *in_split), qgu, *dsplit, rounding=rounding)
+        got = mixedgemm.gate_up_activate_decode(x, idx, qgu, *dsplit, rounding=rounding)
+        assert_same_operands(got, want, m, dsplit, f"decode {m}x{h}x{i} {rounding}")
+    with pytest.raises(RuntimeError):
+        mixedgemm.gate_up_activate_decode(torch.cat([x] * 9)[:9].contiguous(), idx, qgu, *dsplit)      # M = 9: not a decode batch
+
+
 MODELS = [("llama3-8b", 4096, 14336, (2048, 128, 1920), (12288, 1024, 1024)), ("llama3-8b-fp8x", 4096, 14336, (0, 0, 4096), (7168, 512, 6656)),
           ("qwen2.5-14b", 5120, 13824, (3072, 1024, 1024), (11776, 1024, 1024))]
 
