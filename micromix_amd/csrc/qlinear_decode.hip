@@ -363,7 +363,8 @@ int qlinear_decode_supported(int M, int N, const int K[3]) {
     if (M < 1 || M > 8 || Kt * 2 + decode_operand_bytes(M, K) > DECODE_LDS_MAX) return 0;   // at least one staged row must fit
     // layers wide enough for the streaming kernel's workgroup-local quantization (mx_gemm_stream.hip): it beats quantize + GEMM at
     // M = 1 and 2 (gate/up 10.6-12.7 -> 8.5-9.3 us, fused gate + up 18.3-19.0 -> 16.2-17.7) and ties or loses from M = 4 on
-    if (qlinear_stream_supported(M, N, K)) return M <= 2 ? 2 : 1;
+    // (every workgroup repeats the quantization: beyond ~4 rounds of workgroups -- not measured, N > 32768 -- one separate quantize launch is cheaper)
+    if (qlinear_stream_supported(M, N, K)) return (M <= 2 && N <= 32768) ? 2 : 1;
     const int feat = decode_features(N), cus = device_cus();
     const int rounds = ((N + feat - 1) / feat + cus - 1) / cus;
     const int passes = (int)((M * (Kt / 32) + decode::NT - 1) / decode::NT);
