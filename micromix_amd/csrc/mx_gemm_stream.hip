@@ -164,7 +164,10 @@ template <int F, int T16, bool W4, bool QUANT = false>
 struct Ring {
     static constexpr int WP = W4 ? 1 : 2;
     static constexpr int W_BYTES = F * WP * 1024, X_BYTES = QUANT ? 0 : T16 * 2048, SLOT = W_BYTES + X_BYTES;
-    static constexpr int LOADS = ((MM_STREAM_DBG & 16) ? 0 : F * WP) + ((MM_STREAM_DBG & 1) || QUANT ? 0 : 2 * T16) + ((MM_STREAM_DBG & 2) ? 0 : (QUANT ? 1 : 2));
+    // vector-memory instructions of a slab, at least: the second piece of an activation tile is requested only where it holds rows the
+    // launch has (fp4 tiles are one piece; M <= 8: rows 0 .. 7 sit in the first piece of every format).  The counted waits use this
+    // minimum -- with longer slabs behind it a wait lets at most one instruction fewer stay in flight, never one too many.
+    static constexpr int LOADS = ((MM_STREAM_DBG & 16) ? 0 : F * WP) + ((MM_STREAM_DBG & 1) || QUANT ? 0 : T16) + ((MM_STREAM_DBG & 2) ? 0 : (QUANT ? 1 : 2));
 };
 
 // chunks per row of a segment's 128-deep slab: fp4 4, fp6 6, fp8 8 (x 16 bytes)
@@ -200,6 +203,8 @@ __device__ __forceinline__ void stream_body(const GemmArgs &a, const dq::QuantIn
     const int ns[3] = {a.K[0] >> 7, a.K[1] >> 7, a.K[2] >> 7};
     const int c1 = ns[0], c2 = ns[0] + ns[1], T = c2 + ns[2];
     const int wrows = a.N - n0 > BN ? BN : a.N - n0;
+    const bool half_tile = T16 == 1 && a.M <= 8;        // rows 0 .. 7 of a tile are in its first piece: the second is never requested (rows
+                                                        // 8 .. 15 of the LDS image then hold stale bytes; their outputs are never stored)
     const unsigned ring = __builtin_amdgcn_readfirstlane(lds_address(smem) + wave * D * RG::SLOT);   // LDS byte address of slot 0
     const uint8_t *const ringp = smem + wave * D * RG::SLOT;
 
@@ -274,7 +279,9 @@ __device__ __forceinline__ void stream_body(const GemmArgs &a, const dq::QuantIn
 #pragma unroll
             for (int t = 0; t < T16; ++t) {
                 dma16(rx[G], xva[G], s * XC * 16 + 16 * t * xpitch[G], base + RG::W_BYTES + t * 2048);
-                dma16(rx[G], xvb[G], s * XC * 16 + 16 * t * xpitch[G], base + RG::W_BYTES + t * 2048 + 1024);
+                if constexpr (G > 0) {       // (fp4: 16 rows x 4 chunks are one piece)
+                    if (!half_tile) dma16(rx[G], xvb[G], s * XC * 16 + 16 * t * xpitch[G], base + RG::W_BYTES + t * 2048 + 1024);
+                }
             }
         }
     };

@@ -14,7 +14,7 @@ g = torch.Generator().manual_seed(0)
 st = torch.cuda.current_stream().cuda_stream
 pp = lambda t: t.data_ptr() if t.numel() else None
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 16
-for name, N, K, split in (("q/o", 4096, 4096, (2048, 128, 1920)), ("gate/up", 14336, 4096, (2048, 128, 1920)), ("down", 4096, 14336, (12288, 1024, 1024))):
+for name, N, K, split in (("q/o", 4096, 4096, (2048, 128, 1920)), ("gate/up", 14336, 4096, (2048, 128, 1920)), ("gate+up", 28672, 4096, (2048, 128, 1920)), ("down", 4096, 14336, (12288, 1024, 1024))):
     w = (torch.randn((N, K), generator=g) * 0.02).to(torch.bfloat16).to(dev)
     idx = torch.randperm(K, generator=g).to(torch.int16).to(dev)
     b = mixedgemm.reorder_quantize_w4(w, idx, *split)
@@ -31,8 +31,12 @@ for name, N, K, split in (("q/o", 4096, 4096, (2048, 128, 1920)), ("gate/up", 14
     f(); torch.cuda.synchronize()
     c = clock.cpu().numpy()
     c = c[c[:, 0] > 0][:, :5].astype(np.float64) / 100.0          # us
+    if len(c) == 0:
+        print(f"{name:8s} M={M}: not on the streaming kernel ({lib.mm_matmul_describe(M, N, *split, 1, 0, 0).decode()[:60]})"); continue
     t0 = c[:, 0].min()
     ph = np.diff(c, axis=1)
+    starts = np.sort(c[:, 0] - t0); ends = np.sort(c[:, 4] - t0)
+    print(f"   starts (us after the first): 10% {starts[len(c)//10]:.2f} 50% {starts[len(c)//2]:.2f} 90% {starts[9*len(c)//10]:.2f} max {starts[-1]:.2f};  ends: 10% {ends[len(c)//10]:.2f} 50% {ends[len(c)//2]:.2f} 90% {ends[9*len(c)//10]:.2f} max {ends[-1]:.2f}")
     print(f"{name:8s} M={M} N={N} K={K}: {len(c)} workgroups; start spread {c[:, 0].max() - t0:.2f} us; last end {c[:, 4].max() - t0:.2f} us after the first start; "
           f"per workgroup (median / max us): prime {np.median(ph[:, 0]):.2f}/{ph[:, 0].max():.2f}  loop {np.median(ph[:, 1]):.2f}/{ph[:, 1].max():.2f}  "
           f"barrier {np.median(ph[:, 2]):.2f}/{ph[:, 2].max():.2f}  reduce+store {np.median(ph[:, 3]):.2f}/{ph[:, 3].max():.2f}  total {np.median(c[:, 4] - c[:, 0]):.2f}/{(c[:, 4] - c[:, 0]).max():.2f}", flush=True)
