@@ -662,7 +662,8 @@ def main():
                                       "kernel": lib.mm_matmul_describe(m_, nn_, *sp, 1, 4 if wsb else 0, wsb).decode()[:90]}
             del bs_
         sm["note"] = ("back-to-back direct C-ABI launches (mm_matmul_ws with the stream's split-K workspace where the plan wants one); the SAME "
-                      "weights every launch, i.e. served by the 256 MiB Infinity Cache -- `small_m_hbm` rotates through 12 weight sets")
+                      "weights every launch, i.e. served by the 256 MiB Infinity Cache when the allocator's placement lets them stay there (the same "
+                      "launch measures ~7 us in one process and ~9 us in another) -- `small_m_hbm` rotates through 12 weight sets")
         result["small_m"] = sm
         # ---- the same launches with the weights coming from HBM: 12 different gate_proj-sized weight sets in rotation (12 x 31 MB > the
         #      256 MiB Infinity Cache), as consecutive layers of a model would present them ----
