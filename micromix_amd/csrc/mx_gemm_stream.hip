@@ -644,6 +644,9 @@ hipError_t launch_qlinear_stream(const void *X, const int16_t *idx, const uint8_
     a.bias = (const uint16_t *)bias;
     a.D = (uint16_t *)D;
     const bool wide = (N + 31) / 32 >= device_cus();
+    static const int qd = getenv("MICROMIX_DECODE_DEPTH") ? atoi(getenv("MICROMIX_DECODE_DEPTH")) : 2;     // kernel-developer override: ring slots (2, 3, 4)
+    if (wide && qd == 3) return w4 ? launch_quant<2, 3, 8, true>(a, qi, stream) : launch_quant<2, 3, 8, false>(a, qi, stream);
+    if (wide && qd == 4) return w4 ? launch_quant<2, 4, 8, true>(a, qi, stream) : launch_quant<2, 4, 8, false>(a, qi, stream);
     if (wide) return w4 ? launch_quant<2, 2, 8, true>(a, qi, stream) : launch_quant<2, 2, 8, false>(a, qi, stream);
     return w4 ? launch_quant<1, 3, 8, true>(a, qi, stream) : launch_quant<1, 3, 8, false>(a, qi, stream);
 }

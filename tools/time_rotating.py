@@ -7,6 +7,7 @@ import torch
 from micromix_amd import _lib, mixedgemm
 lib = _lib.load(); dev = torch.device("cuda:0")
 M, N, K = (int(v) for v in sys.argv[1:4]); split = tuple(int(v) for v in sys.argv[4].split(",")); R = int(sys.argv[5]) if len(sys.argv) > 5 else 8
+DECODE = len(sys.argv) > 6 and sys.argv[6] == "decode"      # mm_qlinear_decode (quantize + GEMM in one launch) instead of mm_matmul
 g = torch.Generator().manual_seed(0)
 st = torch.cuda.current_stream().cuda_stream
 pp = lambda t: t.data_ptr() if t.numel() else None
@@ -19,9 +20,13 @@ x = torch.randn((M, K), generator=g).to(torch.bfloat16).to(dev)
 a = mixedgemm.reorder_quantize_x(x, idx, *split)
 out = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
 calls = [[pp(t) for t in (a[0], b[0], a[1], b[1], a[2], b[2], a[3], b[3], a[4], b[4], a[5], b[5])] for b in sets]
+dcalls = [[pp(t) for t in b] for b in sets]
 def loop():
-    for p in calls: lib.mm_matmul(*p, M, N, *split, 1, 0, None, out.data_ptr(), st)
-print(lib.mm_matmul_describe(M, N, *split, 1, 0, 0).decode())
+    if DECODE:
+        for p in dcalls: lib.mm_qlinear_decode(x.data_ptr(), idx.data_ptr(), *p, M, N, *split, 1, 0, None, out.data_ptr(), st)
+    else:
+        for p in calls: lib.mm_matmul(*p, M, N, *split, 1, 0, None, out.data_ptr(), st)
+print("mm_qlinear_decode" if DECODE else lib.mm_matmul_describe(M, N, *split, 1, 0, 0).decode())
 res = []
 for blk in range(8):
     for _ in range(5): loop()
