@@ -210,6 +210,9 @@ def llama_layer(dev, lib, mixedgemm, x, steps):
         else:
             mm(mixedgemm.reorder_quantize_x(xm, idx, *in_split), w_qkv)
             o = mm(mixedgemm.reorder_quantize_x(attn, idx, *in_split), w_o)
+        if mixedgemm.qlinear_decode_supported(m, 2 * I, *in_split) == 2 and mixedgemm.down_activate_decode_supported(m, H, *down_split) == 2:
+            gub = mixedgemm.qlinear_decode(o, idx, *w_gu, *in_split)             # quantize + gate | up GEMM in one launch ...
+            return mixedgemm.down_activate_decode(gub, w_down, *down_split)      # ... and down_proj with silu * up + its quantization inside
         if mixedgemm.qlinear_decode_supported(m, 2 * I, *in_split) == 2:
             qh = mixedgemm.gate_up_activate_decode(o, idx, w_gu, *down_split)   # quantize + gate | up GEMM in one launch, then the quantizer
         else:
@@ -263,7 +266,8 @@ def llama_layer(dev, lib, mixedgemm, x, steps):
         ts, tg = measure(fn, xm, attn, max(5, steps if m > 64 else 4 * steps))
         fused_dec = m <= 64 and bool(mixedgemm.qlinear_decode_supported(m, H + 2 * NKV, *in_split))
         mlp_dec = m <= 64 and mixedgemm.qlinear_decode_supported(m, 2 * I, *in_split) == 2     # gate_up_activate_decode: one launch fewer
-        ent = {"launches_per_layer": 7 if m > 64 else ((6 if fused_dec else 8) - (1 if mlp_dec else 0)),
+        mlp_two = mlp_dec and mixedgemm.down_activate_decode_supported(m, H, *down_split) == 2   # ... down_activate_decode: two fewer
+        ent = {"launches_per_layer": 7 if m > 64 else ((6 if fused_dec else 8) - (2 if mlp_two else 1 if mlp_dec else 0)),
                "us_per_layer_stream": round(ts * 1e6, 1), "us_per_layer_graph": round(tg * 1e6, 1) if tg else None,
                "tokens_per_s_stream": round(m / ts, 1), "tokens_per_s_graph": round(m / tg, 1) if tg else None}
         # `tokens_per_s` by a FIXED rule, not the better of the two: prefill-sized batches (M > 64) are GPU-bound and run as stream

@@ -198,6 +198,17 @@ int mm_gate_up_activate_decode(const void *X_bf16, const int16_t *reorder_index,
                                const uint8_t *SFBN, const uint8_t *SFBS, const uint8_t *SFBO, int M, int I, int KN, int KS, int KO, int DN,
                                int DS, int DO, int flags, uint8_t *oN, uint8_t *oS, uint8_t *oO, uint8_t *sfN, uint8_t *sfS, uint8_t *sfO,
                                void *workspace, size_t workspace_bytes, mm_stream_t stream);
+/* The other half of a decode-sized MLP: down_proj straight from the bf16 gate | up matrix GU [M, 2 I] (128 gate columns alternating with
+ * the 128 up columns of the same indices: the layout mm_gate_up_activate's scratch and mm_qlinear_decode on an interleaved weight produce;
+ * 16-byte aligned).  Every workgroup of the weight-streaming GEMM computes silu(gate) * up and quantizes it for its own use -- the
+ * bytes of mm_activate_quantize (activate.cu:44-202) -- so the result equals mm_matmul on mm_activate_quantize's output, in ONE launch
+ * instead of two.  (DN, DS, DO) = down_proj's split of the I intermediate features in natural column order; B / SFB = its packed weights
+ * (mm_downproj_quantize); wmode / flags / bias as mm_matmul.  M <= 4: mm_down_activate_decode_supported() returns 0 if the shape cannot
+ * run, 1 if it can, 2 if it is expected to beat the two-launch form. */
+int mm_down_activate_decode_supported(int M, int N, int DN, int DS, int DO);
+int mm_down_activate_decode(const void *GU_bf16, const uint8_t *BN, const uint8_t *BS, const uint8_t *BO, const uint8_t *SFBN, const uint8_t *SFBS,
+                            const uint8_t *SFBO, int M, int N, int DN, int DS, int DO, int wmode, int flags, const void *bias_bf16, void *D_bf16,
+                            mm_stream_t stream);
 /* which kernels mm_gate_up_activate launches for (M, I) (thread-local buffer, as mm_matmul_describe) */
 const char *mm_gate_up_activate_describe(int M, int I);
 

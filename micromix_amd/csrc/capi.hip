@@ -296,6 +296,31 @@ int mm_gate_up_activate_decode(const void *X_bf16, const int16_t *reorder_index,
     return e == hipSuccess ? MM_OK : fail_hip(e, "mm_gate_up_activate_decode");
 }
 
+int mm_down_activate_decode_supported(int M, int N, int DN, int DS, int DO) {
+    if (M < 1 || N < 1 || DN < 0 || DS < 0 || DO < 0 || (DN % 128) || (DS % 128) || (DO % 128) || DN + DS + DO == 0) return 0;
+    const int K[3] = {DN, DS, DO};
+    if (!mm::down_activate_stream_supported(M, N, K)) return 0;
+    return M <= 2 ? 2 : 1;      // every workgroup repeats silu * up + the quantization: one pass of its threads up to M = 2 at I = 14336
+}
+
+int mm_down_activate_decode(const void *GU_bf16, const uint8_t *BN, const uint8_t *BS, const uint8_t *BO, const uint8_t *SFBN, const uint8_t *SFBS,
+                            const uint8_t *SFBO, int M, int N, int DN, int DS, int DO, int wmode, int flags, const void *bias_bf16, void *D_bf16,
+                            mm_stream_t stream) {
+    if (M < 0 || N < 0 || DN < 0 || DS < 0 || DO < 0) return MM_ERR_BAD_ARG;
+    if ((DN % 128) || (DS % 128) || (DO % 128) || DN + DS + DO == 0) return MM_ERR_BAD_SPLIT;
+    if (wmode != MM_W_MATCH && wmode != MM_W_FP4) return MM_ERR_BAD_ARG;
+    if (flags & ~MM_ROUND_ONCE) return MM_ERR_BAD_ARG;
+    if (M == 0 || N == 0) return MM_OK;
+    if (!mm_down_activate_decode_supported(M, N, DN, DS, DO)) return MM_ERR_UNSUPPORTED;
+    if (!GU_bf16 || !D_bf16 || ((uintptr_t)GU_bf16 & 15)) return MM_ERR_BAD_ARG;
+    if ((DN && (!BN || !SFBN)) || (DS && (!BS || !SFBS)) || (DO && (!BO || !SFBO))) return MM_ERR_BAD_ARG;
+    const uint8_t *W[3] = {BN, BS, BO}, *SFW[3] = {SFBN, SFBS, SFBO};
+    const int K[3] = {DN, DS, DO};
+    hipError_t e = mm::launch_down_activate_stream(GU_bf16, W, SFW, M, N, K, wmode == MM_W_FP4, (flags & MM_ROUND_ONCE) ? 0 : 1, bias_bf16, D_bf16,
+                                                   (hipStream_t)stream);
+    return e == hipSuccess ? MM_OK : fail_hip(e, "mm_down_activate_decode");
+}
+
 int mm_matmul_ws_reset(void *workspace, size_t workspace_bytes, mm_stream_t stream) {
     if (!workspace || workspace_bytes < MM_WS_TICKET_BYTES || ((uintptr_t)workspace & 15)) return MM_ERR_BAD_ARG;
     static_assert(MM_WS_TICKET_BYTES % 16 == 0 && MM_WS_TICKET_BYTES / 16 <= 1024, "one workgroup clears the ticket words");

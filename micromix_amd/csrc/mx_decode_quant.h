@@ -3,6 +3,7 @@
 // reorder.cu:94-269 per group, through the shared quantize_group of mx_group_convert.h: the bytes of reorder_quantize_x.
 #pragma once
 #include "mx_group_convert.h"
+#include "mx_direct_convert.h"
 
 namespace mm {
 namespace dq {
@@ -13,6 +14,9 @@ struct QuantIn {
     int K[3];
     int M;
     int stage_rows;         // activation rows staged in LDS at a time (launcher: as many as fit)
+    int mode;               // 0: X = bf16 rows, reordered by idx (reorder_quantize_x); 1: X = [M, 2 K] bf16 with 128 gate | 128 up columns
+                            // alternating (mm_gate_up_activate's scratch layout), quantized as activate_quantize_x: silu(gate) * up in
+                            // natural column order (activate_rows_to_lds)
     int early;              // quantize_rows_early applies: one batch (stage_rows >= M), at most one group per thread, at most EARLY_RL row loads per thread
 };
 constexpr int EARLY_RL = 4;
@@ -149,6 +153,59 @@ __device__ __forceinline__ LdsMap quantize_rows_early(const QuantIn &a, uint8_t 
         else if (g < gN + gS) byte = quantize_group<EL_FP6>(row, ix, opS + rr * pS + (g - gN) * 24);
         else byte = quantize_group<EL_FP8>(row, ix, opO + rr * pO + (g - gN - gS) * 32);
         scales[rr * Gt + g] = (uint8_t)byte;
+    }
+    __syncthreads();
+    LdsMap m;
+    m.opN = opN; m.opS = opS; m.opO = opO; m.scales = scales;
+    m.pN = pN; m.pS = pS; m.pO = pO; m.Gt = Gt; m.gN = gN; m.gS = gS;
+    return m;
+}
+
+// The activation quantizer as phase 1 (mm_down_activate_decode): h = silu(gate) * up per 32 consecutive intermediate features, the
+// arithmetic of direct_quantize.hip (activate.cu:44-202; shared quantize32 / silu_mul: the same bytes), codes and scale bytes into the LDS
+// map above with K = the intermediate size in natural order.  `request()` as in quantize_rows_to_lds: called once, after the first
+// batch of loads has landed.
+template <int NT, class Hook>
+__device__ __forceinline__ LdsMap activate_rows_to_lds(const QuantIn &a, uint8_t *smem, Hook request) {
+    const int Kt = a.K[0] + a.K[1] + a.K[2], Gt = Kt >> 5;
+    const int gN = a.K[0] >> 5, gS = a.K[1] >> 5;
+    const int pN = a.K[0] >> 1, pS = (a.K[1] >> 2) * 3, pO = a.K[2];
+    uint8_t *opN = smem, *opS = opN + a.M * pN, *opO = opS + a.M * pS;
+    uint8_t *scales = opO + a.M * pO;
+    const int groups = a.M * Gt;
+    for (int t = threadIdx.x; t - (int)threadIdx.x < groups; t += NT) {      // (every thread walks every pass: request() must run everywhere)
+        const bool live = t < groups;
+        const int r = live ? t / Gt : 0, g = live ? t - r * Gt : 0;
+        // group g of row r: 32 gate values at element r * 2 K + (g / 4) * 256 + (g % 4) * 32, the 32 up values 128 elements further
+        const uint4 *pa = reinterpret_cast<const uint4 *>(a.X + (size_t)r * (size_t)(2 * Kt) + (size_t)(g >> 2) * 256u + (size_t)(g & 3) * 32u);
+        uint4 xa[4], xb[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            xa[i] = pa[i];
+            xb[i] = pa[16 + i];
+        }
+        if (t == (int)threadIdx.x) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { MM_DQ_DEVICE_ONLY(asm volatile("" : "+v"(xa[i].x), "+v"(xa[i].y), "+v"(xb[i].x), "+v"(xb[i].y));) }   // the loads have landed
+            request();
+        }
+        if (live) {
+            float v[32];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) unpack8(xa[i], v + 8 * i);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float b[8];
+                unpack8(xb[i], b);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[8 * i + e] = silu_mul(v[8 * i + e], b[e]);
+            }
+            uint32_t byte;
+            if (g < gN) byte = quantize32<EL_FP4, false>(v, opN + r * pN + g * 16);
+            else if (g < gN + gS) byte = quantize32<EL_FP6, false>(v, opS + r * pS + (g - gN) * 24);
+            else byte = quantize32<EL_FP8, false>(v, opO + r * pO + (g - gN - gS) * 32);
+            scales[r * Gt + g] = (uint8_t)byte;
+        }
     }
     __syncthreads();
     LdsMap m;

@@ -30,7 +30,8 @@ __device__ __forceinline__ int scale_exponent_f32(float amax) {
     return e < -127 ? -127 : (e > 127 ? 127 : e);
 }
 
-template <int EL>
+// (GLOBAL_OUT: the fp4 codes leave through a write-through global store; false for destinations in LDS)
+template <int EL, bool GLOBAL_OUT = true>
 __device__ __forceinline__ uint32_t quantize32(const float (&v)[32], uint8_t *__restrict__ out) {
     float amax = 0.0f;
 #pragma unroll
@@ -62,7 +63,7 @@ __device__ __forceinline__ uint32_t quantize32(const float (&v)[32], uint8_t *__
             r = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(r, v[8 * i + 6], v[8 * i + 7], scale, 3);
             w[i] = r;
         }
-        store16<true>(out, w[0], w[1], w[2], w[3]);      // write-through: see store16 (mx_group_convert.h)
+        store16<GLOBAL_OUT>(out, w[0], w[1], w[2], w[3]);      // write-through: see store16 (mx_group_convert.h)
     } else {
         f16v lo, hi;
 #pragma unroll

@@ -363,7 +363,8 @@ __device__ __forceinline__ void stream_body(const GemmArgs &a, const dq::QuantIn
         return cnt > 0;
     };
     if constexpr (QUANT) {
-        if (qi.early) L = dq::quantize_rows_early<NT, D * RG::LOADS>(qi, smem_all, prime);
+        if (qi.mode == 1) L = dq::activate_rows_to_lds<NT>(qi, smem_all, [&]() { prime(); });
+        else if (qi.early) L = dq::quantize_rows_early<NT, D * RG::LOADS>(qi, smem_all, prime);
         else L = dq::quantize_rows_to_lds<NT>(qi, smem_all, [&]() { prime(); });
         const int rr = li < a.M ? li : 0;
         qx[0] = L.opN + rr * L.pN + 16 * h;
@@ -550,16 +551,16 @@ static hipError_t launch_quant(const GemmArgs &a, dq::QuantIn qi, hipStream_t st
     const size_t Kt = (size_t)a.K[0] + a.K[1] + a.K[2], ops = (dq::operand_bytes(a.M, a.K) + 15) & ~(size_t)15;
     // staged bf16 rows: all M if two workgroups still fit a CU's 160 KB, else as many as one workgroup can hold (at least one)
     constexpr size_t LDS_CU = 160 * 1024, LDS_WG = 156 * 1024;
-    size_t rows = a.M;
-    if (2 * (ops + tail + rows * Kt * 2) > LDS_CU) {
+    size_t rows = qi.mode == 1 ? 0 : a.M;       // (mode 1 quantizes straight from global memory: nothing is staged)
+    if (qi.mode != 1 && 2 * (ops + tail + rows * Kt * 2) > LDS_CU) {
         const size_t two = LDS_CU / 2 > ops + tail ? (LDS_CU / 2 - ops - tail) / (Kt * 2) : 0;
         const size_t one = LDS_WG > ops + tail ? (LDS_WG - ops - tail) / (Kt * 2) : 0;
         rows = two >= 1 ? two : one;
         if (rows > (size_t)a.M) rows = a.M;
     }
-    if (rows < 1) return hipErrorInvalidValue;
+    if (rows < 1 && qi.mode != 1) return hipErrorInvalidValue;
     qi.stage_rows = (int)rows;
-    qi.early = (rows >= (size_t)a.M && (size_t)a.M * (Kt / 32) <= 64u * NW && (size_t)a.M * (Kt / 8) <= 64u * NW * dq::EARLY_RL) ? 1 : 0;
+    qi.early = (qi.mode != 1 && rows >= (size_t)a.M && (size_t)a.M * (Kt / 32) <= 64u * NW && (size_t)a.M * (Kt / 8) <= 64u * NW * dq::EARLY_RL) ? 1 : 0;
     static const int early_on = getenv("MICROMIX_DECODE_EARLY") ? atoi(getenv("MICROMIX_DECODE_EARLY")) : 1;   // kernel-developer override
     if (!early_on) qi.early = 0;
     const size_t qbytes = rows * Kt * 2 + ops, lds = qbytes + tail;
@@ -647,6 +648,37 @@ hipError_t launch_qlinear_stream(const void *X, const int16_t *idx, const uint8_
     static const int qd = getenv("MICROMIX_DECODE_DEPTH") ? atoi(getenv("MICROMIX_DECODE_DEPTH")) : 2;     // kernel-developer override: ring slots (2, 3, 4)
     if (wide && qd == 3) return w4 ? launch_quant<2, 3, 8, true>(a, qi, stream) : launch_quant<2, 3, 8, false>(a, qi, stream);
     if (wide && qd == 4) return w4 ? launch_quant<2, 4, 8, true>(a, qi, stream) : launch_quant<2, 4, 8, false>(a, qi, stream);
+    if (wide) return w4 ? launch_quant<2, 2, 8, true>(a, qi, stream) : launch_quant<2, 2, 8, false>(a, qi, stream);
+    return w4 ? launch_quant<1, 3, 8, true>(a, qi, stream) : launch_quant<1, 3, 8, false>(a, qi, stream);
+}
+
+// mm_down_activate_decode: down_proj at M <= 4 straight from the bf16 gate | up matrix -- every workgroup computes silu(gate) * up and
+// quantizes it for its own use (the bytes of mm_activate_quantize), K = the intermediate size in natural order
+bool down_activate_stream_supported(int M, int N, const int K[3]) {
+    (void)N;
+    return M >= 1 && M <= 4 && dq::operand_bytes(M, K) + 48 * 1024 + 64 <= 156 * 1024;
+}
+hipError_t launch_down_activate_stream(const void *GU, const uint8_t *const W[3], const uint8_t *const SFW[3], int M, int N, const int K[3],
+                                       bool w4, int round_per_segment, const void *bias, void *D, hipStream_t stream) {
+    using namespace stream;
+    GemmArgs a = {};
+    dq::QuantIn qi = {};
+    qi.X = (const uint16_t *)GU;
+    qi.M = M;
+    qi.mode = 1;
+    for (int g = 0; g < 3; ++g) {
+        a.W[g] = W[g];
+        a.SFW[g] = SFW[g];
+        a.K[g] = qi.K[g] = K[g];
+    }
+    a.M = M;
+    a.N = N;
+    a.sfx_row_tiles = 1;
+    a.sfw_row_tiles = (N + 127) / 128;
+    a.round_per_segment = round_per_segment;
+    a.bias = (const uint16_t *)bias;
+    a.D = (uint16_t *)D;
+    const bool wide = (N + 31) / 32 >= device_cus();
     if (wide) return w4 ? launch_quant<2, 2, 8, true>(a, qi, stream) : launch_quant<2, 2, 8, false>(a, qi, stream);
     return w4 ? launch_quant<1, 3, 8, true>(a, qi, stream) : launch_quant<1, 3, 8, false>(a, qi, stream);
 }

@@ -157,6 +157,10 @@ bool mx_gemm_stream_supported(int M, int N, const int K[3], bool w4);
 hipError_t launch_mx_gemm_stream(const GemmArgs &a, bool w4, hipStream_t stream);
 bool mx_gemm_stream_grouped_supported(int max_m, int ngroups, int N, const int K[3]);
 hipError_t launch_mx_gemm_stream_grouped(const GroupedGemmArgs &ga, int max_m, bool w4, hipStream_t stream);
+// ... with silu(gate) * up + its quantization inside every workgroup (mm_down_activate_decode)
+bool down_activate_stream_supported(int M, int N, const int K[3]);
+hipError_t launch_down_activate_stream(const void *GU, const uint8_t *const W[3], const uint8_t *const SFW[3], int M, int N, const int K[3],
+                                       bool w4, int round_per_segment, const void *bias, void *D, hipStream_t stream);
 // ... with the quantization of the M <= 8 activation rows inside every workgroup (mm_qlinear_decode)
 bool qlinear_stream_supported(int M, int N, const int K[3]);
 hipError_t launch_qlinear_stream(const void *X, const int16_t *idx, const uint8_t *const W[3], const uint8_t *const SFW[3], int M, int N,

@@ -515,6 +515,52 @@ def gate_up_activate_decode(X, reorder_index, B, DN, DS, DO, *, rounding="refere
     return oN, oS, oO, sfN, sfS, sfO
 
 
+def down_activate_decode_supported(M, N, DN, DS, DO):
+    """0: cannot run; 1: runs; 2: runs and is expected to beat activate_quantize_x + matmul (mm_down_activate_decode_supported)"""
+    return int(_lib.load().mm_down_activate_decode_supported(int(M), int(N), int(DN), int(DS), int(DO)))
+
+
+def down_activate_decode(GU, B, DN, DS, DO, *, bias=None, rounding="reference"):
+    """down_proj(act_fn(gate) * up) for decode-sized batches in ONE launch: GU [M, 2 I] bf16 holds 128 gate columns alternating with the
+    128 up columns of the same indices (what `qlinear_decode` on an `interleave_gate_up` weight returns); B = down_proj packed with
+    `downproj_quantize_w4` / `_w`; (DN, DS, DO) = its split of the I intermediate features.  Bit-identical to
+    `matmul(activate_quantize_x(gate, up, DN, DS, DO), B)`.  M <= 4.  Not an export of the reference module."""
+    lib = _lib.load()
+    dev = GU.device
+    index = dev.index
+    if not (GU.is_cuda and _ok(GU, torch.bfloat16, index)):
+        _check_tensor(GU, "GU", torch.bfloat16)
+    for t in B:
+        if not _ok(t, torch.uint8, index):
+            _check_tensor(t, "operand", torch.uint8, dev)
+    DN, DS, DO = int(DN), int(DS), int(DO)
+    M, I2 = GU.shape
+    I = DN + DS + DO
+    N = B[0].size(0)
+    if I2 != 2 * I or I % 128 or DN % 128 or DS % 128 or DO % 128:
+        _lib.check(_lib.MM_ERR_BAD_SPLIT, "activate_quantize_x")
+    same = B[1].size(1) == DS // 4 * 3 and B[2].size(1) == DO
+    w4 = B[1].size(1) == DS // 2 and B[2].size(1) == DO // 2
+    if B[0].size(1) != DN // 2 or not (same or w4) or B[1].size(0) != N or B[2].size(0) != N:
+        raise RuntimeError("packed weights do not match (DN, DS, DO)")
+    wmode = _lib.MM_W_MATCH if same else _lib.MM_W_FP4
+    if B[3].numel() < _sf_bytes_w(N, DN) or B[4].numel() < _sf_bytes_w(N, DS) or B[5].numel() < _sf_bytes_w(N, DO):
+        raise RuntimeError("weight scale tensors are too small")
+    if rounding not in ("reference", "fused"):
+        raise ValueError("rounding must be 'reference' or 'fused'")
+    flags = _lib.MM_ROUND_PER_SEGMENT if rounding == "reference" else _lib.MM_ROUND_ONCE
+    if bias is not None and (not _ok(bias, torch.bfloat16, index) or bias.numel() != N):
+        _check_tensor(bias, "bias", torch.bfloat16, dev)
+        raise RuntimeError("bias must have N elements")
+    out = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+    with _on_device(index):
+        st = lib.mm_down_activate_decode(_ptr(GU), _ptr(B[0]), _ptr(B[1]), _ptr(B[2]), _ptr(B[3]), _ptr(B[4]), _ptr(B[5]), M, N, DN, DS, DO, wmode,
+                                         flags, _ptr(bias) if bias is not None else None, _ptr(out), _stream_ptr(dev))
+    if st:
+        _lib.check(st, "down_activate_decode")
+    return out
+
+
 def qlinear_decode(X, reorder_index, BN, BS, BO, SFBN, SFBS, SFBO, KN, KS, KO, *, bias=None, rounding="reference", out=None):
     """reorder_quantize_x + matmul (+ bias) of `QLinearLayer.forward` (qLinearLayer.py:58-74) as ONE launch for M <= 8 rows.
 

@@ -274,7 +274,15 @@ class FusedMLP(nn.Module):
         lead = x.shape[:-1]
         x2 = x.reshape(-1, self.hidden).contiguous()
         gu = (self.GU_BN, self.GU_BS, self.GU_BO, self.GU_SFBN, self.GU_SFBS, self.GU_SFBO)
-        if x2.size(0) <= 8 and mixedgemm.qlinear_decode_supported(x2.size(0), 2 * self.inter, *self.in_split) == 2:
+        m = x2.size(0)
+        down = (self.D_BN, self.D_BS, self.D_BO, self.D_SFBN, self.D_SFBS, self.D_SFBO)
+        if m <= 4 and mixedgemm.qlinear_decode_supported(m, 2 * self.inter, *self.in_split) == 2 \
+                and mixedgemm.down_activate_decode_supported(m, self.hidden, *self.down_split) == 2:
+            # decode, TWO launches: reorder + quantize + the gate | up GEMM, then down_proj with silu * up + its quantization inside
+            # every workgroup (the same bytes as the five-launch form)
+            gub = mixedgemm.qlinear_decode(x2, self.reorder_index, *gu, *self.in_split, rounding=self.rounding)
+            return mixedgemm.down_activate_decode(gub, down, *self.down_split, rounding=self.rounding).reshape(*lead, self.hidden)
+        if m <= 8 and mixedgemm.qlinear_decode_supported(m, 2 * self.inter, *self.in_split) == 2:
             # decode: reorder + quantize + the gate | up GEMM in one launch, then the activation quantizer (same bytes, one launch fewer)
             qh = mixedgemm.gate_up_activate_decode(x2, self.reorder_index, gu, *self.down_split, rounding=self.rounding)
         else:

@@ -100,6 +100,35 @@ def test_decode_form_equals_quantize_then_fused(dev, m, h, i, in_split, dsplit):
         mixedgemm.gate_up_activate_decode(torch.cat([x] * 9)[:9].contiguous(), idx, qgu, *dsplit)      # M = 9: not a decode batch
 
 
+# down_proj straight from the bf16 gate | up matrix (mm_down_activate_decode, M <= 4): bit-identical to activate_quantize_x -> matmul;
+# every consumer format, N with a ragged last workgroup, two passes of the in-workgroup quantizer (M * I / 32 > 512), bias, both weight
+# modes, both roundings; Llama's own shapes
+DOWN_DECODE = [(1, 256, 256, (128, 0, 128)), (3, 200, 512, (256, 128, 128)), (4, 1000, 1280, (1024, 128, 128)), (2, 8200, 768, (0, 768, 0)),
+               (1, 4096, 14336, (12288, 1024, 1024)), (2, 4096, 14336, (12288, 1024, 1024))]
+
+
+@pytest.mark.parametrize("wmode", ("w4", "w"))
+@pytest.mark.parametrize("m,n,i,dsplit", DOWN_DECODE, ids=[f"{c[0]}x{c[1]}x{c[2]}" for c in DOWN_DECODE])
+def test_down_from_gate_up_matrix(dev, m, n, i, dsplit, wmode):
+    import torch
+    rng = np.random.default_rng(m * 11 + n + i)
+    gate = t_from_bits(make_inputs(rng, m, i), dev) * 2
+    up = t_from_bits(make_inputs(rng, m, i), dev)
+    wd = t_from_bits(make_inputs(rng, n, i, "weight"), dev)
+    bias = t_from_bits(o.f32_to_bf16(rng.standard_normal(n).astype(np.float32)), dev)
+    gu = torch.stack([gate.reshape(m, i // 128, 128), up.reshape(m, i // 128, 128)], dim=2).reshape(m, 2 * i).contiguous()   # 128 gate | 128 up
+    b = (mixedgemm.downproj_quantize_w4 if wmode == "w4" else mixedgemm.downproj_quantize_w)(wd, *dsplit)
+    assert mixedgemm.down_activate_decode_supported(m, n, *dsplit) >= 1
+    qh = mixedgemm.activate_quantize_x(gate, up, *dsplit)
+    for rounding in ("reference", "fused"):
+        for bv in (None, bias):
+            want = mixedgemm.matmul(qh[0], b[0], qh[1], b[1], qh[2], b[2], qh[3], b[3], qh[4], b[4], qh[5], b[5], bias=bv, rounding=rounding)
+            got = mixedgemm.down_activate_decode(gu, b, *dsplit, bias=bv, rounding=rounding)
+            assert torch.equal(got, want), (m, n, i, dsplit, wmode, rounding, bv is not None)
+    with pytest.raises(RuntimeError):
+        mixedgemm.down_activate_decode(torch.cat([gu] * 5)[:5].contiguous(), b, *dsplit)      # M = 5
+
+
 MODELS = [("llama3-8b", 4096, 14336, (2048, 128, 1920), (12288, 1024, 1024)), ("llama3-8b-fp8x", 4096, 14336, (0, 0, 4096), (7168, 512, 6656)),
           ("qwen2.5-14b", 5120, 13824, (3072, 1024, 1024), (11776, 1024, 1024))]
 
