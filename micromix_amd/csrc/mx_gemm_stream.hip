@@ -645,6 +645,13 @@ hipError_t launch_qlinear_stream(const void *X, const int16_t *idx, const uint8_
     a.bias = (const uint16_t *)bias;
     a.D = (uint16_t *)D;
     const bool wide = (N + 31) / 32 >= device_cus();
+    static const int qf4 = getenv("MICROMIX_DECODE_F4") ? atoi(getenv("MICROMIX_DECODE_F4")) : 0;          // kernel-developer override: 64 features x 4 waves, this many slots (-1: never)
+    if (wide && qf4 == 2) return w4 ? launch_quant<4, 2, 4, true>(a, qi, stream) : launch_quant<4, 2, 4, false>(a, qi, stream);
+    if (wide && qf4 == 3) return w4 ? launch_quant<4, 3, 4, true>(a, qi, stream) : launch_quant<4, 3, 4, false>(a, qi, stream);
+    if (wide && qf4 == 4) return w4 ? launch_quant<4, 4, 4, true>(a, qi, stream) : launch_quant<4, 4, 4, false>(a, qi, stream);
+    // more than one round of 32-feature workgroups (two per CU): 64 features x 4 waves halve the workgroups that repeat the quantization and
+    // run in one round (fused gate + up, N = 28672, M = 1: 17.3 -> 14.2 us, from HBM 18.7 -> 16.1; at N = 14336 it loses 1 us from HBM)
+    if (wide && qf4 == 0 && (N + 31) / 32 > 2 * device_cus()) return w4 ? launch_quant<4, 2, 4, true>(a, qi, stream) : launch_quant<4, 2, 4, false>(a, qi, stream);
     static const int qd = getenv("MICROMIX_DECODE_DEPTH") ? atoi(getenv("MICROMIX_DECODE_DEPTH")) : 2;     // kernel-developer override: ring slots (2, 3, 4)
     if (wide && qd == 3) return w4 ? launch_quant<2, 3, 8, true>(a, qi, stream) : launch_quant<2, 3, 8, false>(a, qi, stream);
     if (wide && qd == 4) return w4 ? launch_quant<2, 4, 8, true>(a, qi, stream) : launch_quant<2, 4, 8, false>(a, qi, stream);
@@ -711,6 +718,9 @@ hipError_t launch_mx_gemm_stream(const GemmArgs &a, bool w4, hipStream_t stream)
 #endif
     // (slots, waves) from sweeps on three boxes (profiles/r04_stream_ablation.txt, section 7): more waves with a shallow ring beat fewer
     // with a deep one; 32 tokens x 32 features: four waves, so that two workgroups fit a CU's LDS
+    // more than one round of 32-feature workgroups (fused gate + up, N = 28672): 64 features x 4 waves run in one round -- the same
+    // time with resident weights, 1 us less at M = 16 when they come from HBM (18.2 -> 17.1; section 19 of the record)
+    if (a.M <= 16 && (a.N + 31) / 32 > 2 * cus) return MM_STREAM(4, 1, 2, 4);
     if (a.M <= 16) return wide ? MM_STREAM(2, 1, 2, 8) : MM_STREAM(1, 1, 3, 8);
     if (a.M <= 32) return wide ? MM_STREAM(2, 2, 3, 4) : MM_STREAM(1, 2, 3, 8);
     // 33 .. 64 tokens: three / four token tiles; two slots of 8 / 10 KB and four waves, so that two workgroups fit a CU's LDS

@@ -492,6 +492,8 @@ STREAM_CASES = [
     (32, 8224, (512, 128, 384)),           # two token tiles, wide, ragged N
     (25, 4100, (0, 256, 2048)),            # two token tiles, no fp4 segment
     (32, 300, (3072, 896, 128)),           # two token tiles, 32 slabs
+    (5, 16640, (256, 128, 256)),           # more than one round of 32-feature workgroups: 64 features x 4 waves (F = 4), half tiles
+    (16, 16424, (128, 256, 1024)),         # ... full tiles, ragged last workgroup (16424 = 256 x 64 + 40)
 ]
 # 32 < M <= 64 (three / four token tiles; the dispatch sends only some of these shapes to the streaming kernel, so it is forced through
 # MICROMIX_MID_M_STREAM in a child process: tests/test_stream_mid_m_gpu.py)
