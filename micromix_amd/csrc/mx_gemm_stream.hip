@@ -656,6 +656,7 @@ hipError_t launch_qlinear_stream(const void *X, const int16_t *idx, const uint8_
     if (wide && qd == 3) return w4 ? launch_quant<2, 3, 8, true>(a, qi, stream) : launch_quant<2, 3, 8, false>(a, qi, stream);
     if (wide && qd == 4) return w4 ? launch_quant<2, 4, 8, true>(a, qi, stream) : launch_quant<2, 4, 8, false>(a, qi, stream);
     if (wide) return w4 ? launch_quant<2, 2, 8, true>(a, qi, stream) : launch_quant<2, 2, 8, false>(a, qi, stream);
+    if (((K[0] + K[1] + K[2]) >> 7) <= 32) return w4 ? launch_quant<1, 4, 8, true>(a, qi, stream) : launch_quant<1, 4, 8, false>(a, qi, stream);
     return w4 ? launch_quant<1, 3, 8, true>(a, qi, stream) : launch_quant<1, 3, 8, false>(a, qi, stream);
 }
 
@@ -721,7 +722,9 @@ hipError_t launch_mx_gemm_stream(const GemmArgs &a, bool w4, hipStream_t stream)
     // more than one round of 32-feature workgroups (fused gate + up, N = 28672): 64 features x 4 waves run in one round -- the same
     // time with resident weights, 1 us less at M = 16 when they come from HBM (18.2 -> 17.1; section 19 of the record)
     if (a.M <= 16 && (a.N + 31) / 32 > 2 * cus) return MM_STREAM(4, 1, 2, 4);
-    if (a.M <= 16) return wide ? MM_STREAM(2, 1, 2, 8) : MM_STREAM(1, 1, 3, 8);
+    const int slabs = (a.K[0] + a.K[1] + a.K[2]) >> 7;
+    // (few features: four slots when a wave's slabs are at most four -- K <= 4096: everything is requested at once, no phantom steps)
+    if (a.M <= 16) return wide ? MM_STREAM(2, 1, 2, 8) : (slabs <= 32 ? MM_STREAM(1, 1, 4, 8) : MM_STREAM(1, 1, 3, 8));
     if (a.M <= 32) return wide ? MM_STREAM(2, 2, 3, 4) : MM_STREAM(1, 2, 3, 8);
     // 33 .. 64 tokens: three / four token tiles; two slots of 8 / 10 KB and four waves, so that two workgroups fit a CU's LDS
     if (a.M <= 48) return wide ? MM_STREAM(2, 3, 2, 4) : MM_STREAM(1, 3, 2, 8);
