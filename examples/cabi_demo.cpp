@@ -2,7 +2,8 @@
 //   hipcc --offload-arch=gfx950 -O2 -I include examples/cabi_demo.cpp -L micromix_amd/lib -lmicromix_hip -Wl,-rpath,$PWD/micromix_amd/lib -o examples/cabi_demo
 // It packs a weight matrix once (reorder_quantize_w4), quantizes activations (reorder_quantize_x), runs the fused GEMM, and checks
 // two exact properties that need no oracle: the result is deterministic, and adding 1 to every activation scale byte doubles it.
-// Then the MLP's front half: mm_gate_up_activate against mm_matmul x 2 + mm_activate_quantize, byte for byte.
+// Then the MLP's front half: mm_gate_up_activate against mm_matmul x 2 + mm_activate_quantize, byte for byte; and a decode-sized MLP in
+// two calls (mm_qlinear_decode, mm_down_activate_decode) against the five it replaces.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -196,5 +197,50 @@ int main(int argc, char **argv) {
     }
     std::printf("fused gate/up (%s): bytes differing from mm_matmul x 2 + mm_activate_quantize: %zu\n",
                 fws_bytes ? "M <= 64: GEMM into scratch + quantizer" : "one launch", fused_diff);
-    return (nondet || nonlinear || fused_diff) ? 1 : 0;
+
+    // ---- the whole MLP for a decode-sized batch (2 token rows) in TWO launches: mm_qlinear_decode on the interleaved gate | up weight
+    //      (reorder + quantize + GEMM), then mm_down_activate_decode (silu(gate) * up + its quantization inside down_proj's GEMM) --
+    //      against the five calls it replaces, byte for byte ----
+    const int MD = 2, ND = 768;                            // down_proj: [ND, I]
+    std::vector<uint16_t> hwd((size_t)ND * I);
+    for (auto &v : hwd) v = bf16(rnd() * 0.05f);
+    uint16_t *dwd, *dScratch, *dOutA, *dOutB;
+    HIP_OK(hipMalloc(&dwd, hwd.size() * 2));
+    HIP_OK(hipMalloc(&dScratch, (size_t)MD * 2 * I * 2));
+    HIP_OK(hipMalloc(&dOutA, (size_t)MD * ND * 2));
+    HIP_OK(hipMalloc(&dOutB, (size_t)MD * ND * 2));
+    HIP_OK(hipMemcpy(dwd, hwd.data(), hwd.size() * 2, hipMemcpyHostToDevice));
+    uint8_t *wd_seg[3], *wd_sf[3];
+    const size_t wdrow[3] = {(size_t)DN / 2, (size_t)DS / 2, (size_t)DO / 2};
+    for (int s = 0; s < 3; ++s) {
+        HIP_OK(hipMalloc(&wd_seg[s], ND * wdrow[s] + 16));
+        HIP_OK(hipMalloc(&wd_sf[s], mm_sf_bytes_w(ND, dwidths[s]) + 16));
+    }
+    MM_CALL(mm_downproj_quantize(dwd, ND, DN, DS, DO, MM_QUANT_W4, wd_seg[0], wd_seg[1], wd_seg[2], wd_sf[0], wd_sf[1], wd_sf[2], stream));
+    size_t decode_diff = 0;
+    if (mm_qlinear_decode_supported(MD, 2 * I, KN, KS, KO) && mm_down_activate_decode_supported(MD, ND, DN, DS, DO)) {
+        // five calls: quantize x, gate | up GEMM + activation quantizer (mm_gate_up_activate: two launches at this size), down GEMM
+        MM_CALL(mm_reorder_quantize(dx, MD, K, didx, KN, KS, KO, MM_QUANT_MIXED, qx.seg[0], qx.seg[1], qx.seg[2], qx.sf[0], qx.sf[1], qx.sf[2], stream));
+        void *ws2 = nullptr;
+        const size_t ws2_bytes = mm_gate_up_activate_workspace_bytes(MD, I);
+        if (ws2_bytes) HIP_OK(hipMalloc(&ws2, ws2_bytes));
+        MM_CALL(mm_gate_up_activate(qx.seg[0], qgu.seg[0], qx.seg[1], qgu.seg[1], qx.seg[2], qgu.seg[2], qx.sf[0], qgu.sf[0], qx.sf[1], qgu.sf[1],
+                                    qx.sf[2], qgu.sf[2], MD, I, KN, KS, KO, DN, DS, DO, MM_ROUND_PER_SEGMENT, t_seg[0], t_seg[1], t_seg[2], t_sf[0],
+                                    t_sf[1], t_sf[2], ws2, ws2_bytes, stream));
+        MM_CALL(mm_matmul(t_seg[0], wd_seg[0], t_seg[1], wd_seg[1], t_seg[2], wd_seg[2], t_sf[0], wd_sf[0], t_sf[1], wd_sf[1], t_sf[2], wd_sf[2],
+                          MD, ND, DN, DS, DO, MM_W_FP4, MM_ROUND_PER_SEGMENT, nullptr, dOutA, stream));
+        // two calls
+        MM_CALL(mm_qlinear_decode(dx, didx, qgu.seg[0], qgu.seg[1], qgu.seg[2], qgu.sf[0], qgu.sf[1], qgu.sf[2], MD, 2 * I, KN, KS, KO, MM_W_FP4,
+                                  MM_ROUND_PER_SEGMENT, nullptr, dScratch, stream));
+        MM_CALL(mm_down_activate_decode(dScratch, wd_seg[0], wd_seg[1], wd_seg[2], wd_sf[0], wd_sf[1], wd_sf[2], MD, ND, DN, DS, DO, MM_W_FP4,
+                                        MM_ROUND_PER_SEGMENT, nullptr, dOutB, stream));
+        HIP_OK(hipStreamSynchronize(stream));
+        std::vector<uint16_t> ya((size_t)MD * ND), yb(ya.size());
+        HIP_OK(hipMemcpy(ya.data(), dOutA, ya.size() * 2, hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(yb.data(), dOutB, yb.size() * 2, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < ya.size(); ++i) decode_diff += ya[i] != yb[i];
+        std::printf("decode MLP (2 rows): outputs of mm_qlinear_decode -> mm_down_activate_decode differing from the five-call form: %zu of %zu\n",
+                    decode_diff, ya.size());
+    }
+    return (nondet || nonlinear || fused_diff || decode_diff) ? 1 : 0;
 }
