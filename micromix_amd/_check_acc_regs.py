@@ -6,7 +6,7 @@ names an accumulator register of its kernel.  Lives in the package because micro
 `python tools/check_acc_regs.py [-DFLAG ...]` is the command-line front end (exit code 1 on a violation)."""
 import os, re, subprocess, sys, tempfile
 PKG = os.path.dirname(os.path.abspath(__file__))
-NACC = {"g256": 128, "g128": 64, "g64": 32, "g32": 0, "g32n": 0}   # the 4-wave tiles leave their accumulators to the compiler
+NACC = {"g256w": 256, "g256": 128, "g128": 64, "g64": 32, "g32": 0, "g32n": 0, "g16": 0}   # the 4-wave tiles leave their accumulators to the compiler
 ASM_OWN = re.compile(r"^\s*(v_mfma_scale_f32_32x32x64_f8f6f4|v_accvgpr_read_b32|v_accvgpr_write_b32)\b")
 
 
@@ -20,7 +20,7 @@ def agprs(line):
     return out
 
 
-EXPECTED_KERNELS = 16   # g256: 2 + 2 grouped + 1 fused gate/up; g128: 2 + 2 split-K + 2 grouped + 1 fused gate/up; g64: 2 + 2 grouped
+EXPECTED_KERNELS = 17   # g256w: 1; g256: 2 + 2 grouped + 1 fused gate/up; g128: 2 + 2 split-K + 2 grouped + 1 fused gate/up; g64: 2 + 2 grouped
 
 
 def check(asm_text):
@@ -32,7 +32,7 @@ def check_counted(asm_text):
     """(violations, symbols of the kernels with asm-owned accumulators that were examined).  A caller must also require
     len(examined) >= EXPECTED_KERNELS: a name-mangling change would otherwise make the check pass with nothing examined."""
     bad, examined = [], []
-    for m in re.finditer(r"^(_ZN2mm\d(g(?:256|128|64|32n|32))(?:17|21|25)mx_gemm256_(?:grouped_|act_)?kernel\w*):[^\n]*\n(.*?)\.end_amdhsa_kernel",
+    for m in re.finditer(r"^(_ZN2mm\d(g(?:256w|256|128|64|32n|32|16))(?:17|21|25)mx_gemm256_(?:grouped_|act_)?kernel\w*):[^\n]*\n(.*?)\.end_amdhsa_kernel",
                          asm_text, re.S | re.M):
         sym, ns, body = m.group(1), m.group(2), m.group(3)
         n = NACC[ns]
@@ -51,6 +51,109 @@ def check_counted(asm_text):
                 continue
             bad.append((sym, code.strip()))
     return bad, examined
+
+
+# ---------------------------------------------------------------------------------------------------------
+# mx_gemm_stream.hip (the weight-streaming kernels, every M <= 64 path): NACC = 12 * F * T16 accumulators a[0 : NACC-1] named only by
+# inline asm, and registers that the hardware writes asynchronously AFTER the asm statement that requested them has returned
+# (buffer_load_dwordx2 / global_load_dwordx4 issued from asm with "=&v" outputs, merged across the segment branches).  Three checks per
+# kernel: (1) as above, no instruction but the asm's own names an accumulator; (2) no scratch (a spilled accumulator copy or pending
+# load destination would be silently wrong); (3) no instruction reads -- or overwrites -- the destination of a vector-memory load before an
+# s_waitcnt vmcnt that covers it (vmcnt counts loads, stores and LDS-DMA together, in issue order; basic-block boundaries reset
+# the model, so the scan is exact for straight-line code and silent across branches).
+# ---------------------------------------------------------------------------------------------------------
+STREAM_OWN = re.compile(r"^\s*(v_mfma_scale_f32_16x16x128_f8f6f4|v_accvgpr_read_b32|v_accvgpr_write_b32)\b")
+STREAM_KERNEL = re.compile(r"^(_ZN2mm6stream\d+(mx_gemm_stream_kernel|mx_gemm_stream_grouped_kernel|mx_qlinear_stream_kernel)I((?:Li\d+E)+)Lb[01]E\w*):[^\n]*\n(.*?)\.end_amdhsa_kernel",
+                           re.S | re.M)
+EXPECTED_STREAM_KERNELS = 52   # 20 plain + 16 grouped + 16 with the quantizer inside
+VMEM = re.compile(r"^\s*(buffer_|global_|scratch_|flat_)(load|store|atomic)")
+
+
+def vgprs(text):
+    out = []
+    for m in re.finditer(r"\bv\[(\d+):(\d+)\]", text):
+        out += list(range(int(m.group(1)), int(m.group(2)) + 1))
+    for m in re.finditer(r"\bv(\d+)\b", text):
+        out.append(int(m.group(1)))
+    return out
+
+
+def stream_nacc(kind, ints):
+    """accumulator registers of an instantiation, from the template arguments in its mangled name: <F, T16, D, NW> (plain, grouped) or
+    <F, D, NW> with T16 = 1 (quantizer inside)"""
+    v = [int(x) for x in re.findall(r"Li(\d+)E", ints)]
+    f, t16 = (v[0], 1) if kind == "mx_qlinear_stream_kernel" else (v[0], v[1])
+    return 12 * f * t16
+
+
+def pending_load_violations(body):
+    """check (3): instructions that touch the destination of a load still counted in vmcnt"""
+    bad, pending = [], []          # pending: per outstanding VMEM op, the set of destination VGPRs (empty for stores / LDS-DMA)
+    for line in body.split("\n"):
+        code = line.split(";")[0].strip()
+        if not code:
+            continue
+        if code.endswith(":") or code.startswith("s_cbranch") or code.startswith("s_branch") or code.startswith("s_setpc") or code.startswith("s_endpgm"):
+            pending = []
+            continue
+        if code.startswith("."):
+            continue
+        m = re.match(r"s_waitcnt\b(.*)", code)
+        if m:
+            v = re.search(r"vmcnt\((\d+)\)", m.group(1))
+            if v:
+                n = int(v.group(1))
+                pending = pending[len(pending) - n:] if n else []
+            continue
+        live = set().union(*pending) if pending else set()
+        if live:
+            hit = [r for r in vgprs(code) if r in live]
+            if hit:
+                bad.append(code)
+        if VMEM.match(code):
+            dst = set()
+            if re.match(r"^\s*(buffer|global|scratch|flat)_load", code) and " lds" not in code and not code.rstrip().endswith("lds"):
+                first = code.split(None, 1)[1].split(",")[0]
+                dst = set(vgprs(first))
+            pending.append(dst)
+    return bad
+
+
+def check_stream(asm_text):
+    """(violations, kernels examined) for the assembly of mx_gemm_stream.hip"""
+    bad, examined = [], []
+    for m in STREAM_KERNEL.finditer(asm_text):
+        sym, kind, ints, body = m.group(1), m.group(2), m.group(3), m.group(4)
+        n = stream_nacc(kind, ints)
+        examined.append(sym)
+        for line in body.split("\n"):
+            code = line.split(";")[0]
+            if not code.strip():
+                continue
+            if code.strip().startswith("."):
+                sm = re.match(r"\s*\.amdhsa_private_segment_fixed_size\s+(\d+)", code)
+                if sm and int(sm.group(1)) != 0:
+                    bad.append((sym, f"scratch: {sm.group(1)} bytes per lane (spill)"))
+                continue
+            regs = [r for r in agprs(code) if r < n]
+            if not regs:
+                continue
+            if STREAM_OWN.match(code) is not None and not re.search(r"\ba\d+\b", code):
+                continue
+            bad.append((sym, code.strip()))
+        bad += [(sym, "reads a load destination before its s_waitcnt vmcnt: " + c) for c in pending_load_violations(body)]
+    return bad, examined
+
+
+def verify_stream(asm_text):
+    bad, examined = check_stream(asm_text)
+    if bad:
+        raise RuntimeError("mx_gemm_stream.hip: hipcc touched asm-owned registers of a streaming kernel (results would be corrupted):\n" +
+                           "\n".join(f"  {s}: {c}" for s, c in bad[:10]))
+    if len(examined) < EXPECTED_STREAM_KERNELS:
+        raise RuntimeError(f"accumulator-register check found {len(examined)} streaming kernels, expected >= {EXPECTED_STREAM_KERNELS} "
+                           "(kernel names changed? update micromix_amd/_check_acc_regs.py)")
+    return len(examined)
 
 
 def verify(asm_text):

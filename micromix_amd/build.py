@@ -55,17 +55,20 @@ def needs_build() -> bool:
     return False
 
 
-GUARDED = "mx_gemm256.hip"     # its 8-wave tile kernels keep their accumulators in asm-owned AGPRs: _check_acc_regs.py
+# sources whose kernels keep accumulators (and, in the streaming kernels, pending load destinations) in registers that only inline asm
+# names: _check_acc_regs.py examines the assembly of every build of them
+GUARDED = {"mx_gemm256.hip": "verify", "mx_gemm_stream.hip": "verify_stream"}
 
 
-def verify_acc_regs(objdir: str = OBJDIR) -> int:
-    """The assembly hipcc generated for mx_gemm256.hip (kept by -save-temps=obj) must not touch an accumulator AGPR outside
-    the inline asm; raises RuntimeError otherwise.  Part of every build of that file, whatever its flags."""
+def verify_acc_regs(objdir: str = OBJDIR, src: str = "mx_gemm256.hip") -> int:
+    """The assembly hipcc generated for a guarded source (kept by -save-temps=obj) must not touch an asm-owned register outside
+    the inline asm; raises RuntimeError otherwise.  Part of every build of those files, whatever its flags."""
     from . import _check_acc_regs as check_acc_regs
-    asm = [f for f in os.listdir(objdir) if f.startswith("mx_gemm256") and f.endswith(".s") and "gfx950" in f]
+    stem = src.replace(".hip", "")
+    asm = [f for f in os.listdir(objdir) if f.startswith(stem + "-") and f.endswith(".s") and "gfx950" in f]
     if not asm:
-        raise RuntimeError("no device assembly of mx_gemm256.hip found (was it compiled with -save-temps=obj?)")
-    return check_acc_regs.verify(open(os.path.join(objdir, asm[0])).read())
+        raise RuntimeError(f"no device assembly of {src} found (was it compiled with -save-temps=obj?)")
+    return getattr(check_acc_regs, GUARDED[src])(open(os.path.join(objdir, asm[0])).read())
 
 
 def _flags_stamp() -> str:
@@ -93,18 +96,19 @@ def build(force: bool = False, keep_temps: bool = False, verbose: bool = True, e
     def compile_one(src):
         s, obj = os.path.join(CSRC, src), os.path.join(OBJDIR, src.replace(".hip", ".o"))
         if force or _stale(obj, ht, s):
-            guarded = src == GUARDED and "-save-temps=obj" not in flags
+            guarded = src in GUARDED and "-save-temps=obj" not in flags
             cmd = [cc, *flags, *(["-save-temps=obj"] if guarded else []), "-c", s, "-o", obj]
             if verbose:
                 print("[micromix_amd.build]", " ".join(cmd), flush=True)
             subprocess.check_call(cmd, cwd=OBJDIR)
-            if src == GUARDED:
-                n = verify_acc_regs(OBJDIR)       # a violation fails the build: the library would compute wrong GEMMs
+            if src in GUARDED:
+                n = verify_acc_regs(OBJDIR, src)  # a violation fails the build: the library would compute wrong GEMMs
                 if verbose:
-                    print(f"[micromix_amd.build] accumulator-register guard: {n} tile kernels clean", flush=True)
+                    print(f"[micromix_amd.build] asm-owned register guard, {src}: {n} kernels clean", flush=True)
                 if guarded:                       # the temporaries were kept for the guard only
+                    stem = src.replace(".hip", "")
                     for f in os.listdir(OBJDIR):
-                        if f.startswith("mx_gemm256") and f != "mx_gemm256.o":
+                        if f.startswith(stem + "-") or (f.startswith(stem + ".") and f != stem + ".o"):
                             os.remove(os.path.join(OBJDIR, f))
         return obj
 

@@ -18,6 +18,10 @@ static int fail_hip(hipError_t e, const char *where) {
     return MM_ERR_LAUNCH;
 }
 
+// The weight mode a launch really runs in: MM_W_FP4 as given; MM_W_MATCH with KS = KO = 0 has only the N segment, whose weights are
+// fp4 in both modes, so it takes the fp4-weight kernels too (the matching-precision 256 x 256 kernel sits at its register limit).
+static bool weights_fp4(int wmode, int KS, int KO) { return wmode == MM_W_FP4 || (KS == 0 && KO == 0); }
+
 static bool split_ok(int K, int KN, int KS, int KO) {
     return KN >= 0 && KS >= 0 && KO >= 0 && (KN % 128) == 0 && (KS % 128) == 0 && (KO % 128) == 0 && KN + KS + KO == K &&
            K > 0;
@@ -128,7 +132,7 @@ int mm_qlinear_decode(const void *X_bf16, const int16_t *reorder_index, const ui
     if ((KN && (!BN || !SFBN)) || (KS && (!BS || !SFBS)) || (KO && (!BO || !SFBO))) return MM_ERR_BAD_ARG;
     const uint8_t *W[3] = {BN, BS, BO}, *SFW[3] = {SFBN, SFBS, SFBO};
     const int K[3] = {KN, KS, KO};
-    hipError_t e = mm::launch_qlinear_decode(X_bf16, reorder_index, W, SFW, M, N, K, wmode == MM_W_FP4,
+    hipError_t e = mm::launch_qlinear_decode(X_bf16, reorder_index, W, SFW, M, N, K, weights_fp4(wmode, KS, KO),
                                              (flags & MM_ROUND_ONCE) ? 0 : 1, bias_bf16, D_bf16, (hipStream_t)stream);
     return e == hipSuccess ? MM_OK : fail_hip(e, "mm_qlinear_decode");
 }
@@ -136,16 +140,16 @@ int mm_qlinear_decode(const void *X_bf16, const int16_t *reorder_index, const ui
 size_t mm_matmul_workspace_bytes(int M, int N, int KN, int KS, int KO, int wmode, int flags) {
     if (M <= 0 || N <= 0 || KN < 0 || KS < 0 || KO < 0 || (KN % 128) || (KS % 128) || (KO % 128)) return 0;
     const int K[3] = {KN, KS, KO};
-    return mm::mx_gemm_workspace_bytes(M, N, K, wmode == MM_W_FP4, (flags & MM_SPLIT_K_ALWAYS) != 0, (flags & MM_WS_TICKETS_ZEROED) != 0);
+    return mm::mx_gemm_workspace_bytes(M, N, K, weights_fp4(wmode, KS, KO), (flags & MM_SPLIT_K_ALWAYS) != 0, (flags & MM_WS_TICKETS_ZEROED) != 0);
 }
 
 const char *mm_matmul_describe(int M, int N, int KN, int KS, int KO, int wmode, int flags, size_t workspace_bytes) {
     if (M <= 0 || N <= 0 || KN < 0 || KS < 0 || KO < 0 || (KN % 128) || (KS % 128) || (KO % 128) || KN + KS + KO == 0) return "none";
     const int K[3] = {KN, KS, KO};
-    if (M <= 64 && !mm::mx_gemm_small_m_uses_tiles(M, N, K, wmode == MM_W_FP4, workspace_bytes, (flags & MM_SPLIT_K_ALWAYS) != 0))
-        return mm::mx_gemm_stream_supported(M, N, K, wmode == MM_W_FP4) ? "mm::stream::mx_gemm_stream_kernel (weight streaming, M <= 64)"
+    if (M <= 64 && !mm::mx_gemm_small_m_uses_tiles(M, N, K, weights_fp4(wmode, KS, KO), workspace_bytes, (flags & MM_SPLIT_K_ALWAYS) != 0))
+        return mm::mx_gemm_stream_supported(M, N, K, weights_fp4(wmode, KS, KO)) ? "mm::stream::mx_gemm_stream_kernel (weight streaming, M <= 64)"
                                                                          : "mm::skinny::mx_gemm_skinny*_kernel (weight streaming, M <= 64)";
-    return mm::describe_mx_gemm256(M, N, K, wmode == MM_W_FP4, workspace_bytes, (flags & MM_SPLIT_K_ALWAYS) != 0, (flags & MM_WS_TICKETS_ZEROED) != 0);
+    return mm::describe_mx_gemm256(M, N, K, weights_fp4(wmode, KS, KO), workspace_bytes, (flags & MM_SPLIT_K_ALWAYS) != 0, (flags & MM_WS_TICKETS_ZEROED) != 0);
 }
 
 int mm_matmul(const uint8_t *AN, const uint8_t *BN, const uint8_t *AS, const uint8_t *BS, const uint8_t *AO,
@@ -202,7 +206,7 @@ int mm_matmul_ws(const uint8_t *AN, const uint8_t *BN, const uint8_t *AS, const 
     a.n_tile0 = a.n_tiles = 0;
     a.force_split = (flags & MM_SPLIT_K_ALWAYS) ? 1 : 0;
     a.split_first[0] = a.split_first[1] = a.split_first[2] = a.split_first[3] = 0;
-    hipError_t e = mm::launch_mx_gemm(a, wmode == MM_W_FP4, (hipStream_t)stream);
+    hipError_t e = mm::launch_mx_gemm(a, weights_fp4(wmode, KS, KO), (hipStream_t)stream);
     return e == hipSuccess ? MM_OK : fail_hip(e, "mm_matmul");
 }
 
@@ -316,7 +320,7 @@ int mm_down_activate_decode(const void *GU_bf16, const uint8_t *BN, const uint8_
     if ((DN && (!BN || !SFBN)) || (DS && (!BS || !SFBS)) || (DO && (!BO || !SFBO))) return MM_ERR_BAD_ARG;
     const uint8_t *W[3] = {BN, BS, BO}, *SFW[3] = {SFBN, SFBS, SFBO};
     const int K[3] = {DN, DS, DO};
-    hipError_t e = mm::launch_down_activate_stream(GU_bf16, W, SFW, M, N, K, wmode == MM_W_FP4, (flags & MM_ROUND_ONCE) ? 0 : 1, bias_bf16, D_bf16,
+    hipError_t e = mm::launch_down_activate_stream(GU_bf16, W, SFW, M, N, K, weights_fp4(wmode, DS, DO), (flags & MM_ROUND_ONCE) ? 0 : 1, bias_bf16, D_bf16,
                                                    (hipStream_t)stream);
     return e == hipSuccess ? MM_OK : fail_hip(e, "mm_down_activate_decode");
 }
@@ -423,8 +427,8 @@ int mm_matmul_grouped(const mm_group *groups, int ngroups, int N, int KN, int KS
         small.ngroups = nsmall;
         const int Ks[3] = {KN, KS, KO};
         hipError_t e = mm::mx_gemm_stream_grouped_supported(max_m, nsmall, N, Ks)
-                           ? mm::launch_mx_gemm_stream_grouped(small, max_m, wmode == MM_W_FP4, (hipStream_t)stream)
-                           : mm::launch_mx_gemm_skinny_grouped(small, max_m, wmode == MM_W_FP4, (hipStream_t)stream);
+                           ? mm::launch_mx_gemm_stream_grouped(small, max_m, weights_fp4(wmode, KS, KO), (hipStream_t)stream)
+                           : mm::launch_mx_gemm_skinny_grouped(small, max_m, weights_fp4(wmode, KS, KO), (hipStream_t)stream);
         nsmall = 0;
         max_m = 0;
         return e == hipSuccess ? MM_OK : fail_hip(e, "mm_matmul_grouped");
@@ -432,7 +436,7 @@ int mm_matmul_grouped(const mm_group *groups, int ngroups, int N, int KN, int KS
     auto flush_big = [&]() -> int {
         if (nbig == 0) return MM_OK;
         big.ngroups = nbig;
-        hipError_t e = mm::launch_mx_gemm256_grouped(big, wmode == MM_W_FP4, (hipStream_t)stream);
+        hipError_t e = mm::launch_mx_gemm256_grouped(big, weights_fp4(wmode, KS, KO), (hipStream_t)stream);
         nbig = 0;
         return e == hipSuccess ? MM_OK : fail_hip(e, "mm_matmul_grouped");
     };

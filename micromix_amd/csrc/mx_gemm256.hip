@@ -85,6 +85,25 @@ namespace mm {
 #undef MM_ACC
 #undef MM_MAX_STAGES
 #undef MM_LDS_BUDGET
+// The same 256 x 256 tile with ONE wave per SIMD (round 5): 4 waves as 2 x 2, 128 x 128 outputs = 4 x 4 MFMA tiles
+// per wave, all 256 AGPRs are accumulators, 4 + 4 fragment reads per 16 MFMAs instead of 2 + 4 per 8.
+#define MM_NS g256w
+#define MM_MAX_STAGES 3
+#define MM_LDS_BUDGET (160 * 1024)
+#define MM_WM 2
+#define MM_TM 4
+#define MM_TN 4
+#define MM_W1 1
+#define MM_ACC MM_ACC_CLOBBER256
+#include "mx_gemm_tile.inc"
+#undef MM_NS
+#undef MM_WM
+#undef MM_TM
+#undef MM_TN
+#undef MM_W1
+#undef MM_ACC
+#undef MM_MAX_STAGES
+#undef MM_LDS_BUDGET
 #define MM_NS g128
 #define MM_MAX_STAGES 3
 #define MM_LDS_BUDGET (160 * 1024)
@@ -491,6 +510,17 @@ bool mx_gemm_small_m_uses_tiles(int M, int N, const int K[3], bool w4, size_t ws
     return need > 0 && need <= ws_bytes;
 }
 
+// 256 x 256 tiles: the one-wave-per-SIMD kernel (g256w) instead of the 8-wave one?  fp4 weights only.  MICROMIX_GEMM_W1 = 0 never,
+// 1 always, unset: the measured rule below.
+static bool use_w1(const int K[3], bool w4) {
+    static const int pin = env_int("MICROMIX_GEMM_W1", -1);
+    if (!w4 || pin == 0) return false;
+    // A/B of round 5 (profiles/r05_w1_ab.txt): equal on the fp4 x fp4 segment (-1 %), 4-12 % slower wherever an fp6 or fp8 activation segment
+    // runs -- one wave per SIMD pays its LDS-DMA issue stalls and its own ds_read latency out of its own MFMA stream.  Never by default.
+    (void)K;
+    return pin == 1;
+}
+
 const char *describe_mx_gemm256(int M, int N, const int K[3], bool w4, size_t ws_bytes, bool force_split, bool tickets_zeroed) {
     static thread_local char buf[192];
     const TilePlan p = plan_tiles(M, N, K, w4, ws_bytes > 0, ws_bytes, force_split, tickets_zeroed);
@@ -503,7 +533,10 @@ const char *describe_mx_gemm256(int M, int N, const int K[3], bool w4, size_t ws
         case TK_G32N: snprintf(buf, sizeof(buf), "mm::g32n::mx_gemm256_kernel<%s,false> x %d workgroups (64x64 tiles)", w, p.tiles32n); break;
         case TK_G16: snprintf(buf, sizeof(buf), "mm::g16::mx_gemm256_kernel<%s,false> x %d workgroups (32x64 tiles)", w, p.tiles16); break;
         case TK_G256_TAIL: snprintf(buf, sizeof(buf), "mm::g256::mx_gemm256_kernel<%s,false> x %d workgroups (256x256 tiles) + mm::g128::mx_gemm256_kernel<%s,false> x %d (last %d tile columns as 128x256 tiles)", w, p.tm256 * (p.tn - p.tail_cols), w, p.tm128 * p.tail_cols, p.tail_cols); break;
-        case TK_G256: snprintf(buf, sizeof(buf), "mm::g256::mx_gemm256_kernel<%s,false> x %d workgroups (256x256 tiles)", w, p.tiles256); break;
+        case TK_G256:
+            if (use_w1(K, w4)) snprintf(buf, sizeof(buf), "mm::g256w::mx_gemm256_kernel<true,false> x %d workgroups (256x256 tiles, one wave per SIMD)", p.tiles256);
+            else snprintf(buf, sizeof(buf), "mm::g256::mx_gemm256_kernel<%s,false> x %d workgroups (256x256 tiles)", w, p.tiles256);
+            break;
         default: snprintf(buf, sizeof(buf), "mm::g128::mx_gemm256_kernel<%s,false> x %d workgroups (128x256 tiles)", w, p.tiles128); break;
     }
     return buf;
@@ -587,6 +620,10 @@ hipError_t launch_mx_gemm256(const GemmArgs &a, bool w4, hipStream_t stream) {
                       : launch_tile(g128::mx_gemm256_kernel<false, false>, done[3], g128::Lds<false>::TOTAL, p.tm128 * c, g128::NT, hi, stream);
         }
         case TK_G256:
+            if (use_w1(a.K, w4)) {
+                static DynamicLdsOnce dw1;
+                return launch_tile(g256w::mx_gemm256_kernel<true, false>, dw1, g256w::Lds<true>::TOTAL, p.tiles256, g256w::NT, a, stream);
+            }
             if (w4) return launch_tile(g256::mx_gemm256_kernel<true, false>, done[0], g256::Lds<true>::TOTAL, p.tiles256, g256::NT, a, stream);
             return launch_tile(g256::mx_gemm256_kernel<false, false>, done[1], g256::Lds<false>::TOTAL, p.tiles256, g256::NT, a, stream);
         default:

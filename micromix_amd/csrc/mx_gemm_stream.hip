@@ -270,17 +270,22 @@ __device__ __forceinline__ void stream_body(const GemmArgs &a, const dq::QuantIn
         }
         if constexpr (!(MM_STREAM_DBG & 16)) {
 #pragma unroll
+            // The row-tile term goes into the per-lane offset, NOT into soffset: a raw buffer's range check covers inst_offset + voffset
+            // only, so with it in soffset a lane whose row lies inside the descriptor's range would fetch rows past N (the
+            // last workgroup when N is not a multiple of 16 F).  Unsigned: OOB + the term stays past every range and below 2^32.
             for (int f = 0; f < F; ++f) {
-                dma16(rw[G], wva[G], s * WC * 16 + 16 * f * wpitch[G], base + f * RG::WP * 1024);
-                if constexpr (!W4) dma16(rw[G], wvb[G], s * WC * 16 + 16 * f * wpitch[G], base + f * RG::WP * 1024 + 1024);
+                const int ft = 16 * f * wpitch[G];
+                dma16(rw[G], (int)((unsigned)wva[G] + (unsigned)ft), s * WC * 16, base + f * RG::WP * 1024);
+                if constexpr (!W4) dma16(rw[G], (int)((unsigned)wvb[G] + (unsigned)ft), s * WC * 16, base + f * RG::WP * 1024 + 1024);
             }
         }
         if constexpr (!(MM_STREAM_DBG & 1) && !QUANT) {
 #pragma unroll
-            for (int t = 0; t < T16; ++t) {
-                dma16(rx[G], xva[G], s * XC * 16 + 16 * t * xpitch[G], base + RG::W_BYTES + t * 2048);
+            for (int t = 0; t < T16; ++t) {      // (as above: token rows past M -- M = 17 .. 31 with two tiles -- must fail the range check)
+                const int tt = 16 * t * xpitch[G];
+                dma16(rx[G], (int)((unsigned)xva[G] + (unsigned)tt), s * XC * 16, base + RG::W_BYTES + t * 2048);
                 if constexpr (G > 0) {       // (fp4: 16 rows x 4 chunks are one piece)
-                    if (!half_tile) dma16(rx[G], xvb[G], s * XC * 16 + 16 * t * xpitch[G], base + RG::W_BYTES + t * 2048 + 1024);
+                    if (!half_tile) dma16(rx[G], (int)((unsigned)xvb[G] + (unsigned)tt), s * XC * 16, base + RG::W_BYTES + t * 2048 + 1024);
                 }
             }
         }
@@ -564,6 +569,7 @@ static hipError_t launch_quant(const GemmArgs &a, dq::QuantIn qi, hipStream_t st
     static const int early_on = getenv("MICROMIX_DECODE_EARLY") ? atoi(getenv("MICROMIX_DECODE_EARLY")) : 1;   // kernel-developer override
     if (!early_on) qi.early = 0;
     const size_t qbytes = rows * Kt * 2 + ops, lds = qbytes + tail;
+    if (lds > LDS_WG) return hipErrorInvalidValue;      // (every mode: the supported() predicates keep callers away from this)
     static DynamicLdsOnce once;
     if (lds > 65536) {
         hipError_t e = once.ensure(reinterpret_cast<const void *>(mx_qlinear_stream_kernel<F, D, NW, W4>), (int)LDS_WG);
@@ -612,6 +618,12 @@ bool mx_gemm_stream_supported(int M, int N, const int K[3], bool w4) {
     return true;
 }
 
+// LDS that the ring / reduction tail of the quantizing launches may need beside the quantization's own range: the largest of the
+// instantiations launch_quant is called with -- matching-precision weights, NW * D * SLOT = 8 * 2 * 4096 = 4 * 2 * 8192 = 8 * 4 * 2048
+// = 64 KB (fp4 weights: 48 KB).  The supported() predicates budget this worst case so that a shape they accept always launches
+// (they budgeted 48 KB whatever the weight mode).
+constexpr size_t STREAM_TAIL_BUDGET = 64 * 1024;
+
 // 1 if mm_qlinear_decode can run on the streaming kernel (the quantized rows, one staged row and the rings fit a workgroup's LDS)
 bool qlinear_stream_supported(int M, int N, const int K[3]) {
     static const int on = getenv("MICROMIX_DECODE_STREAM") ? atoi(getenv("MICROMIX_DECODE_STREAM")) : 1;   // kernel-developer override
@@ -619,9 +631,9 @@ bool qlinear_stream_supported(int M, int N, const int K[3]) {
     // it wins where N / 32 fills the CUs and one pass quantizes the rows (gate/up at M = 1 / 2 / 4: 12.5 / 11.8 / 14.3 -> 10.2 / 9.2 /
     // 12.3 us) and loses on q/k/v/o (few workgroups: all start-up) and at M = 8 (two passes per workgroup: quantize + GEMM wins there).
     const size_t Kt = (size_t)K[0] + K[1] + K[2];
-    if (on == 2 && M >= 1 && M <= 8) return dq::operand_bytes(M, K) + Kt * 2 + 48 * 1024 + 64 <= 156 * 1024;     // (A/B runs: every shape that fits)
+    if (on == 2 && M >= 1 && M <= 8) return dq::operand_bytes(M, K) + Kt * 2 + STREAM_TAIL_BUDGET + 64 <= 156 * 1024;     // (A/B runs: every shape that fits)
     if (!on || M < 1 || M > 4 || (N + 31) / 32 < device_cus()) return false;
-    return dq::operand_bytes(M, K) + Kt * 2 + 48 * 1024 + 64 <= 156 * 1024;
+    return dq::operand_bytes(M, K) + Kt * 2 + STREAM_TAIL_BUDGET + 64 <= 156 * 1024;
 }
 
 hipError_t launch_qlinear_stream(const void *X, const int16_t *idx, const uint8_t *const W[3], const uint8_t *const SFW[3], int M, int N,
@@ -664,7 +676,7 @@ hipError_t launch_qlinear_stream(const void *X, const int16_t *idx, const uint8_
 // quantizes it for its own use (the bytes of mm_activate_quantize), K = the intermediate size in natural order
 bool down_activate_stream_supported(int M, int N, const int K[3]) {
     (void)N;
-    return M >= 1 && M <= 4 && dq::operand_bytes(M, K) + 48 * 1024 + 64 <= 156 * 1024;
+    return M >= 1 && M <= 4 && dq::operand_bytes(M, K) + STREAM_TAIL_BUDGET + 64 <= 156 * 1024;
 }
 hipError_t launch_down_activate_stream(const void *GU, const uint8_t *const W[3], const uint8_t *const SFW[3], int M, int N, const int K[3],
                                        bool w4, int round_per_segment, const void *bias, void *D, hipStream_t stream) {

@@ -152,7 +152,7 @@ bool mx_gemm_act_supported(int M, int N);                                 // the
 hipError_t launch_mx_gemm_act(const GemmArgs &a, hipStream_t stream);    // fp4 weights only
 const char *describe_mx_gemm_act(int M, int N);
 hipError_t launch_mx_gemm_skinny(const GemmArgs &a, bool w4, hipStream_t stream);
-// second-generation weight-streaming kernel (mx_gemm_stream.hip): M <= 32
+// second-generation weight-streaming kernel (mx_gemm_stream.hip): M <= 64 (one to four 16-token tiles)
 bool mx_gemm_stream_supported(int M, int N, const int K[3], bool w4);
 hipError_t launch_mx_gemm_stream(const GemmArgs &a, bool w4, hipStream_t stream);
 bool mx_gemm_stream_grouped_supported(int max_m, int ngroups, int N, const int K[3]);

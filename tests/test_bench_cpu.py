@@ -49,3 +49,47 @@ def test_matmul_describe_names_the_dispatch():
     assert "g32n" in d(256, 4096, 0, 0, 4096, 1, 0, 0) and "256 workgroups (64x64 tiles)" in d(256, 4096, 0, 0, 4096, 1, 0, 0)
     assert "g32::" in d(512, 4096, 0, 0, 4096, 1, 0, 0) and "(64x128 tiles)" in d(512, 4096, 0, 0, 4096, 1, 0, 0)
     assert "g64" in d(1024, 4096, 0, 0, 4096, 1, 0, 0) and "g128" in d(2048, 4096, 0, 0, 4096, 1, 0, 0)
+
+
+def test_compact_line_fits_the_driver_record():
+    """the ONE printed line stays under 6 KB and still carries `mixed`, `power`, `zero_operands` as numbers; the
+    canned full result is round 4's own bench output (profiles/r04_summary.txt)."""
+    import json
+    with open(os.path.join(ROOT, "tests", "golden", "bench_result_r04.json")) as f:
+        full = json.load(f)
+    assert len(json.dumps(full)) > 12000                      # what the driver's tail could not hold
+    line = bench.compact_line(full, "gpurun_out/bench_details.json")
+    assert len(line) < bench.LINE_LIMIT == 6144 and "\n" not in line
+    d = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["value"] == full["value"] and d["config"]["workload"].startswith("BASELINE.json configs[1]")
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(d["roofline"])
+    assert d["roofline"]["zero_operands"]["kernel_us"] == full["roofline"]["zero_operands"]["kernel_us"]
+    assert d["power"]["package_w"] == full["power"]["package_w"]
+    assert d["mixed"]["q_o_all_fp4"] == [full["mixed"]["q_o_all_fp4"]["kernel_us"], full["mixed"]["q_o_all_fp4"]["frac"]]
+    assert {"value", "unit", "cores", "kind", "sample"} <= set(d["cpu_baseline"])
+    assert d["llama_layer"]["1"]["us"] == full["llama_layer"]["by_rows"]["1"]["us_per_layer_graph"]
+    # an oversized result sheds extras, never contract keys
+    fat = dict(full, small_m={f"case{i}": dict(full["small_m"]["down_M16"]) for i in range(400)})
+    line = bench.compact_line(fat, None)
+    assert len(line) < bench.LINE_LIMIT and {"metric", "value", "roofline", "cpu_baseline", "mixed"} <= set(json.loads(line))
+
+
+def test_gpus_n_without_rendezvous_launches_its_own_ranks():
+    """`python bench.py --gpus 2` (no WORLD_SIZE) starts torch.distributed.run as a CHILD and returns its exit
+    code.  On this CPU-only box the ranks stop at "needs an MI355X": what is checked is the hop -- two ranks were started with a
+    rendezvous on 127.0.0.1 and their failure is the parent's exit code (not a SystemExit about WORLD_SIZE)."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["MICROMIX_BENCH_BACKEND"] = "gloo"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    import torch
+    if torch.cuda.is_available():
+        assert p.returncode == 0, p.stderr[-1500:]
+        return
+    assert p.returncode != 0
+    assert "launching the ranks" in p.stderr and "--nproc-per-node=2" in p.stderr and "--master-addr 127.0.0.1" in p.stderr
+    assert "needs an MI355X" in p.stderr and "launch with torch.distributed.run" not in p.stderr

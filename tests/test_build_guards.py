@@ -77,3 +77,65 @@ def test_every_csrc_header_is_a_build_dependency():
     listed = {os.path.basename(h) for h in build.HEADERS}
     present = {f for f in os.listdir(build.CSRC) if f.endswith((".h", ".inc"))}
     assert present <= listed, sorted(present - listed)
+
+
+STREAM_OK = ("_ZN2mm6stream21mx_gemm_stream_kernelILi2ELi1ELi2ELi8ELb1EEEvNS_8GemmArgsE: ; @x\n"
+             "\tbuffer_load_dwordx2 v[10:11], v17, s[8:11], s1 offen\n"
+             "\tbuffer_load_dwordx4 v18, s[12:15], s2 offen lds\n"
+             "\tv_add_u32_e32 v3, v4, v5\n"
+             "\ts_waitcnt vmcnt(1)\n"
+             "\tv_lshrrev_b32_e32 v6, 8, v10\n"
+             "\tv_mfma_scale_f32_16x16x128_f8f6f4 a[0:3], v[20:23], v[24:27], a[0:3], v6, v7 op_sel_hi:[0,0,0] cbsz:4 blgp:4\n"
+             "\tv_accvgpr_read_b32 v1, a[23]\n"
+             "\t.amdhsa_private_segment_fixed_size 0\n"
+             ".end_amdhsa_kernel\n")
+
+
+def test_the_stream_guard_detects_planted_violations():
+    """mx_gemm_stream.hip keeps 12 F T16 accumulators in asm-owned AGPRs and reads registers the hardware fills after the asm
+    statement returned: accumulator touched by the compiler, scratch, and a load destination read
+    before its wait are each reported; the clean text is clean; NACC follows the template arguments in the mangled name."""
+    import check_acc_regs
+    from micromix_amd import _check_acc_regs as c
+    assert c.stream_nacc("mx_gemm_stream_kernel", "Li2ELi4ELi2ELi4E") == 96 and c.stream_nacc("mx_qlinear_stream_kernel", "Li4ELi2ELi4E") == 48
+    bad, examined = c.check_stream(STREAM_OK)
+    assert not bad and len(examined) == 1
+    # (F, T16) = (2, 1): a[0:23] are accumulators, a24 is the compiler's
+    assert not c.check_stream(STREAM_OK.replace("\tv_add_u32_e32 v3, v4, v5\n", "\tv_accvgpr_write_b32 a24, v2\n"))[0]
+    planted = {
+        "compiler temporary in an accumulator": STREAM_OK.replace("\tv_add_u32_e32 v3, v4, v5\n", "\tv_accvgpr_write_b32 a5, v2\n"),
+        "LDS read into accumulators": STREAM_OK.replace("\tv_add_u32_e32 v3, v4, v5\n", "\tds_read_b128 a[20:23], v9\n"),
+        "scratch": STREAM_OK.replace("fixed_size 0", "fixed_size 16"),
+        "load destination read before its wait": STREAM_OK.replace("\tv_add_u32_e32 v3, v4, v5\n", "\tv_add_u32_e32 v3, v11, v5\n"),
+        "wait that leaves the load in flight": STREAM_OK.replace("vmcnt(1)", "vmcnt(2)"),
+    }
+    for what, text in planted.items():
+        assert c.check_stream(text)[0], what
+    with pytest.raises(RuntimeError, match="asm-owned registers"):
+        c.verify_stream(planted["scratch"])
+    with pytest.raises(RuntimeError, match="expected >="):
+        c.verify_stream(STREAM_OK)                      # one kernel where 52 are expected: the name regex no longer matches
+    assert check_acc_regs                                # (tools/ front end imports)
+
+
+def test_the_build_guards_both_sources(tmp_path):
+    from micromix_amd import build
+    assert set(build.GUARDED) == {"mx_gemm256.hip", "mx_gemm_stream.hip"}
+    with pytest.raises(RuntimeError, match="no device assembly of mx_gemm_stream.hip"):
+        build.verify_acc_regs(str(tmp_path), "mx_gemm_stream.hip")
+    (tmp_path / "mx_gemm_stream-hip-amdgcn-amd-amdhsa-gfx950.s").write_text(STREAM_OK.replace("fixed_size 0", "fixed_size 8"))
+    with pytest.raises(RuntimeError, match="asm-owned registers"):
+        build.verify_acc_regs(str(tmp_path), "mx_gemm_stream.hip")
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc")
+def test_compiler_leaves_the_stream_kernels_registers_alone():
+    from micromix_amd import _check_acc_regs as c
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, "k.s")
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-fno-gpu-rdc", "-S",
+                        "--cuda-device-only", os.path.join(ROOT, "micromix_amd", "csrc", "mx_gemm_stream.hip"), "-o", out],
+                       check=True, cwd=tmp, stderr=subprocess.DEVNULL)
+        bad, examined = c.check_stream(open(out).read())
+    assert len(examined) >= c.EXPECTED_STREAM_KERNELS, len(examined)
+    assert not bad, "\n".join(f"{s}: {x}" for s, x in bad[:10])
