@@ -184,13 +184,20 @@ def llama_layer(dev, lib, mixedgemm, x, steps):
     idx = torch.argsort(x.float().abs().mean(0)).to(torch.int16)
     pack = lambda w: mixedgemm.reorder_quantize_w4(w, idx, *in_split)
     mm = lambda a, b, **kw: mixedgemm.matmul(a[0], b[0], a[1], b[1], a[2], b[2], a[3], b[3], a[4], b[4], a[5], b[5], **kw)
-    w_qkv = pack(torch.cat([rnd(H, H), rnd(NKV, H), rnd(NKV, H)], 0))
-    w_o = pack(rnd(H, H))
-    pg, pu = pack(rnd(I, H)), pack(rnd(I, H))
-    w_gu = mixedgemm.interleave_gate_up(pg, pu)
-    w_gu_cat = tuple(torch.cat((a, b), 0).contiguous() for a, b in zip(pg, pu))
-    del pg, pu
-    w_down = mixedgemm.downproj_quantize_w4(rnd(H, I), *down_split)
+
+    def make_layer(with_cat=False):
+        """one decoder layer's packed weights (116 MB): q | k | v, o, gate | up interleaved per 128 features, down"""
+        L = {"qkv": pack(torch.cat([rnd(H, H), rnd(NKV, H), rnd(NKV, H)], 0)), "o": pack(rnd(H, H))}
+        pg, pu = pack(rnd(I, H)), pack(rnd(I, H))
+        L["gu"] = mixedgemm.interleave_gate_up(pg, pu)
+        if with_cat:
+            L["gu_cat"] = tuple(torch.cat((a, b), 0).contiguous() for a, b in zip(pg, pu))
+        del pg, pu
+        L["down"] = mixedgemm.downproj_quantize_w4(rnd(H, I), *down_split)
+        return L
+
+    layer0 = make_layer(with_cat=True)
+    w_qkv, w_o, w_gu, w_gu_cat, w_down = layer0["qkv"], layer0["o"], layer0["gu"], layer0["gu_cat"], layer0["down"]
     normw = torch.ones((H,), dtype=torch.bfloat16, device=dev)
 
     def prefill(xm, attn):
@@ -202,23 +209,36 @@ def llama_layer(dev, lib, mixedgemm, x, steps):
         qh = mixedgemm.gate_up_activate(qm, w_gu, *down_split)
         return mm(qh, w_down)
 
-    def decode(xm, attn):
+    def decode(xm, attn, L=None):
+        """the layer as a model runs it at M <= 8 (round 5): input_layernorm + q | k | v in ONE launch (rmsnorm_qlinear_decode), o_proj
+        (quantize + GEMM in one launch), post_attention_layernorm + gate | up in ONE launch, down_proj with silu * up + its quantization
+        inside: four launches, norms included"""
+        L = layer0 if L is None else L
         m = xm.size(0)
-        if mixedgemm.qlinear_decode_supported(m, H + 2 * NKV, *in_split):
-            mixedgemm.qlinear_decode(xm, idx, *w_qkv, *in_split)          # quantize + GEMM in one launch
-            o = mixedgemm.qlinear_decode(attn, idx, *w_o, *in_split)
+        if mixedgemm.rmsnorm_qlinear_decode_supported(m, H + 2 * NKV, *in_split):
+            mixedgemm.rmsnorm_qlinear_decode(xm, normw, 1e-5, idx, *L["qkv"], *in_split)      # norm + quantize + GEMM in one launch
         else:
-            mm(mixedgemm.reorder_quantize_x(xm, idx, *in_split), w_qkv)
-            o = mm(mixedgemm.reorder_quantize_x(attn, idx, *in_split), w_o)
-        if mixedgemm.qlinear_decode_supported(m, 2 * I, *in_split) == 2 and mixedgemm.down_activate_decode_supported(m, H, *down_split) == 2:
-            gub = mixedgemm.qlinear_decode(o, idx, *w_gu, *in_split)             # quantize + gate | up GEMM in one launch ...
-            return mixedgemm.down_activate_decode(gub, w_down, *down_split)      # ... and down_proj with silu * up + its quantization inside
-        if mixedgemm.qlinear_decode_supported(m, 2 * I, *in_split) == 2:
-            qh = mixedgemm.gate_up_activate_decode(o, idx, w_gu, *down_split)   # quantize + gate | up GEMM in one launch, then the quantizer
+            mm(mixedgemm.rmsnorm_quantize_x(xm, normw, 1e-5, idx, *in_split), L["qkv"])
+        if mixedgemm.qlinear_decode_supported(m, H, *in_split):
+            o = mixedgemm.qlinear_decode(attn, idx, *L["o"], *in_split)
         else:
-            qm = mixedgemm.reorder_quantize_x(o, idx, *in_split)
-            qh = mixedgemm.gate_up_activate(qm, w_gu, *down_split)        # M <= 64: GEMM into scratch + the quantizer on it
-        return mm(qh, w_down)
+            o = mm(mixedgemm.reorder_quantize_x(attn, idx, *in_split), L["o"])
+        fused_gu = mixedgemm.rmsnorm_qlinear_decode_supported(m, 2 * I, *in_split) == 2
+        if fused_gu and mixedgemm.down_activate_decode_supported(m, H, *down_split) == 2:
+            gub = mixedgemm.rmsnorm_qlinear_decode(o, normw, 1e-5, idx, *L["gu"], *in_split)   # norm + quantize + gate | up GEMM in one launch ...
+            return mixedgemm.down_activate_decode(gub, L["down"], *down_split)                  # ... and down_proj with silu * up + its quantization inside
+        qm = mixedgemm.rmsnorm_quantize_x(o, normw, 1e-5, idx, *in_split)
+        qh = mixedgemm.gate_up_activate(qm, L["gu"], *down_split)        # M <= 64: GEMM into scratch + the quantizer on it
+        return mm(qh, L["down"])
+
+    def launches(m):
+        if m > 64:
+            return 7
+        n = 1 if mixedgemm.rmsnorm_qlinear_decode_supported(m, H + 2 * NKV, *in_split) else 2
+        n += 1 if mixedgemm.qlinear_decode_supported(m, H, *in_split) else 2
+        if mixedgemm.rmsnorm_qlinear_decode_supported(m, 2 * I, *in_split) == 2 and mixedgemm.down_activate_decode_supported(m, H, *down_split) == 2:
+            return n + 2
+        return n + 4            # rmsnorm_quantize_x, gate | up GEMM, activation quantizer, down GEMM
 
     def measure(fn, xm, attn, reps):
         for _ in range(3):
@@ -264,10 +284,7 @@ def llama_layer(dev, lib, mixedgemm, x, steps):
         attn = (x[:m] * 0.5).contiguous()
         fn = prefill if m > 64 else decode
         ts, tg = measure(fn, xm, attn, max(5, steps if m > 64 else 4 * steps))
-        fused_dec = m <= 64 and bool(mixedgemm.qlinear_decode_supported(m, H + 2 * NKV, *in_split))
-        mlp_dec = m <= 64 and mixedgemm.qlinear_decode_supported(m, 2 * I, *in_split) == 2     # gate_up_activate_decode: one launch fewer
-        mlp_two = mlp_dec and mixedgemm.down_activate_decode_supported(m, H, *down_split) == 2   # ... down_activate_decode: two fewer
-        ent = {"launches_per_layer": 7 if m > 64 else ((6 if fused_dec else 8) - (2 if mlp_two else 1 if mlp_dec else 0)),
+        ent = {"launches_per_layer": launches(m),
                "us_per_layer_stream": round(ts * 1e6, 1), "us_per_layer_graph": round(tg * 1e6, 1) if tg else None,
                "tokens_per_s_stream": round(m / ts, 1), "tokens_per_s_graph": round(m / tg, 1) if tg else None}
         # `tokens_per_s` by a FIXED rule, not the better of the two: prefill-sized batches (M > 64) are GPU-bound and run as stream
@@ -278,6 +295,45 @@ def llama_layer(dev, lib, mixedgemm, x, steps):
                     "tokens_per_s_mode": "one hipGraph of the layer's launches (M <= 64)" if use_graph else "stream launches (M > 64)",
                     "tflops": round(flop_per_row * m / t_rule / 1e12, 2)})
         out["by_rows"][str(m)] = ent
+    # ---- decode from HBM: NL layers' weight sets (NL x 116 MB > the 256 MiB Infinity Cache) in rotation inside ONE hipGraph, as consecutive
+    # layers of a model present them; against 116 MB per layer at 8 TB/s ----
+    NL, ROUNDS = 4, 3
+    layers = [layer0] + [make_layer() for _ in range(NL - 1)]
+    wbytes = sum(t.numel() for k in ("qkv", "o", "gu", "down") for t in layer0[k])
+    out["hbm"] = {}
+    out["hbm_note"] = (f"{NL} layers' packed weights ({NL * wbytes / 1e6:.0f} MB) in rotation, {ROUNDS} x {NL} layers per hipGraph replay; "
+                       f"hbm_frac = ({wbytes / 1e6:.1f} MB per layer / 8 TB/s) / time per layer")
+    for m in (8, 1):
+        xm, attn = x[:m].contiguous(), (x[:m] * 0.5).contiguous()
+        try:
+            for L in layers:
+                decode(xm, attn, L)
+            torch.cuda.synchronize()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                decode(xm, attn, layers[0])
+            torch.cuda.current_stream().wait_stream(side)
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr):
+                for _ in range(ROUNDS):
+                    for L in layers:
+                        decode(xm, attn, L)
+            for _ in range(3):
+                gr.replay()
+            torch.cuda.synchronize()
+            reps = 10
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                gr.replay()
+            torch.cuda.synchronize()
+            t_layer = (time.perf_counter() - t0) / (reps * ROUNDS * NL)
+            out["hbm"][str(m)] = {"us_per_layer": round(t_layer * 1e6, 1), "tokens_per_s": round(m / t_layer, 1),
+                                  "weight_bytes_per_layer": wbytes, "hbm_frac": round(wbytes / 8e12 / t_layer, 4)}
+            del gr
+        except Exception as e:
+            print(f"[bench] decode-from-HBM measurement failed at M = {m} ({e})", file=sys.stderr)
+    del layers
     # the MLP at M = 4096 both ways (events around 10 back-to-back repetitions; quantize_x excluded: it is the same launch in both)
     xm = x[:4096].contiguous()
     qm = mixedgemm.reorder_quantize_x(xm, idx, *in_split)

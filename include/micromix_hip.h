@@ -260,6 +260,20 @@ int mm_qlinear_decode(const void *X_bf16, const int16_t *reorder_index, const ui
                       const uint8_t *SFBN, const uint8_t *SFBS, const uint8_t *SFBO, int M, int N, int KN, int KS, int KO,
                       int wmode, int flags, const void *bias_bf16, void *D_bf16, mm_stream_t stream);
 
+/*
+ * The same with the RMSNorm that precedes q/k/v and gate/up in the reference's decoder layers inside the launch (reference:
+ * rmsnorm_quantize_x, mgemm/src/rmsnorm.cu:95-352 / bindings.cpp:257-303, followed by matmul; model/qLlamaLayer.py input_layernorm ->
+ * q/k/v, post_attention_layernorm -> gate/up): every workgroup computes the row's sum of squares in the reference's summation order,
+ * v = bf16((x * w) * rvar), the reference's integer rounding, and quantizes.  Bit-identical to mm_rmsnorm_quantize followed by
+ * mm_matmul.  Needs K <= 8192 besides the conditions of mm_qlinear_decode; X and norm_weight 16-byte aligned.
+ *   flags: MM_ROUND_* | MM_NORM_NO_INTEGER_ROUND (= mm_rmsnorm_quantize's MM_RMS_NO_INTEGER_ROUND)
+ */
+#define MM_NORM_NO_INTEGER_ROUND 0x100
+int mm_rmsnorm_qlinear_decode_supported(int M, int N, int KN, int KS, int KO);
+int mm_rmsnorm_qlinear_decode(const void *X_bf16, const void *norm_weight_bf16, float eps, const int16_t *reorder_index, const uint8_t *BN,
+                              const uint8_t *BS, const uint8_t *BO, const uint8_t *SFBN, const uint8_t *SFBS, const uint8_t *SFBO, int M, int N,
+                              int KN, int KS, int KO, int wmode, int flags, const void *bias_bf16, void *D_bf16, mm_stream_t stream);
+
 /* Which kernel(s) and how many workgroups mm_matmul / mm_matmul_ws launch for this problem on the CURRENT device (the same
  * decision code as the launcher; workspace_bytes = 0 means "no workspace", i.e. never split-K).  Returns a string in a
  * thread-local buffer, valid until the calling thread's next call.  Used by bench.py to name the kernel it timed. */

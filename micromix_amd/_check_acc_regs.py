@@ -126,8 +126,16 @@ def check_stream(asm_text):
         sym, kind, ints, body = m.group(1), m.group(2), m.group(3), m.group(4)
         n = stream_nacc(kind, ints)
         examined.append(sym)
-        for line in body.split("\n"):
-            code = line.split(";")[0]
+        lines = [l.split(";")[0] for l in body.split("\n")]
+        # The accumulators come to life at the kernel's first asm-owned instruction (acc_zero, placed BEHIND the quantization phase of the
+        # kernels that quantize their rows themselves).  In front of it the compiler may park values in those AGPRs -- provided the code in
+        # front of it can never run again: no branch at or behind that point may target a label defined in front of it.
+        first = next((k for k, c in enumerate(lines) if STREAM_OWN.match(c) and re.search(r"\ba\[", c)), len(lines))
+        early_labels = {m2.group(1) for c in lines[:first] for m2 in [re.match(r"^(\.?\w+):\s*$", c.strip())] if m2}
+        reentered = [c.strip() for c in lines[first:] if re.match(r"\s*s_c?branch\w*\s", c) and c.split()[-1] in early_labels]
+        for c in reentered:
+            bad.append((sym, "branches back in front of the first accumulator instruction: " + c))
+        for k, code in enumerate(lines):
             if not code.strip():
                 continue
             if code.strip().startswith("."):
@@ -140,6 +148,8 @@ def check_stream(asm_text):
                 continue
             if STREAM_OWN.match(code) is not None and not re.search(r"\ba\d+\b", code):
                 continue
+            if k < first:
+                continue            # the accumulators are not live yet (see above)
             bad.append((sym, code.strip()))
         bad += [(sym, "reads a load destination before its s_waitcnt vmcnt: " + c) for c in pending_load_violations(body)]
     return bad, examined

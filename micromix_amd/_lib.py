@@ -18,7 +18,7 @@ EXPORTS = (
     "mm_sf_bytes_x", "mm_sf_bytes_w", "mm_sf_offset",
     "mm_reorder_quantize", "mm_reorder_quantize_gather", "mm_activate_quantize", "mm_downproj_quantize", "mm_matmul",
     "mm_matmul_ws", "mm_matmul_workspace_bytes", "mm_matmul_ws_reset",
-    "mm_gate_up_activate", "mm_gate_up_activate_decode", "mm_down_activate_decode", "mm_down_activate_decode_supported", "mm_gate_up_activate_workspace_bytes", "mm_gate_up_activate_describe", "mm_rmsnorm_quantize", "mm_qlinear_decode", "mm_qlinear_decode_supported", "mm_matmul_grouped", "mm_reorder_quantize_grouped",
+    "mm_gate_up_activate", "mm_gate_up_activate_decode", "mm_down_activate_decode", "mm_down_activate_decode_supported", "mm_gate_up_activate_workspace_bytes", "mm_gate_up_activate_describe", "mm_rmsnorm_quantize", "mm_qlinear_decode", "mm_qlinear_decode_supported", "mm_rmsnorm_qlinear_decode", "mm_rmsnorm_qlinear_decode_supported", "mm_matmul_grouped", "mm_reorder_quantize_grouped",
     "mm_matmul_describe", "mm_test_function", "mm_diag_set_kernel_events",
 )
 # every symbol include/micromix_diag.h declares (libmicromix_diag.so: hardware probes for tests/tools, never used by the ops)
@@ -31,6 +31,7 @@ MM_W_MATCH, MM_W_FP4 = 0, 1
 MM_ROUND_PER_SEGMENT, MM_ROUND_ONCE, MM_SPLIT_K_ALWAYS, MM_WS_TICKETS_ZEROED, MM_OUT_F32 = 0, 1, 2, 4, 8
 MM_WS_TICKET_BYTES = 4096
 MM_RMS_REFERENCE, MM_RMS_NO_INTEGER_ROUND = 0, 1
+MM_NORM_NO_INTEGER_ROUND = 0x100
 
 class MMGroup(ctypes.Structure):
     """mm_group of include/micromix_hip.h"""
@@ -89,6 +90,10 @@ def load():
     lib.mm_qlinear_decode.argtypes = [vp] * 8 + [i] * 7 + [vp, vp, vp]
     lib.mm_qlinear_decode_supported.restype = i
     lib.mm_qlinear_decode_supported.argtypes = [i] * 5
+    lib.mm_rmsnorm_qlinear_decode.restype = i
+    lib.mm_rmsnorm_qlinear_decode.argtypes = [vp, vp, ctypes.c_float] + [vp] * 7 + [i] * 7 + [vp, vp, vp]
+    lib.mm_rmsnorm_qlinear_decode_supported.restype = i
+    lib.mm_rmsnorm_qlinear_decode_supported.argtypes = [i] * 5
     lib.mm_reorder_quantize_grouped.restype = i
     lib.mm_reorder_quantize_grouped.argtypes = [ctypes.POINTER(MMQuantGroup), i, i, i, i, i, i, vp]
     lib.mm_matmul_grouped.restype = i

@@ -24,7 +24,7 @@ DIAG_LIB = os.path.join(LIBDIR, "libmicromix_diag.so")
 SOURCES = ["capi.hip", "reorder_quantize.hip", "direct_quantize.hip", "rmsnorm_quantize.hip", "mx_gemm.hip", "mx_gemm256.hip",
            "mx_gemm_skinny.hip", "mx_gemm_stream.hip", "qlinear_decode.hip"]
 DIAG_SOURCES = ["diag.hip"]
-HEADERS = ["mx_common.h", "mx_kernels.h", "mx_acc_regs.h", "mx_gemm_tile.inc", "mx_group_convert.h", "mx_instrument.h", "mx_direct_convert.h", "mx_decode_quant.h",
+HEADERS = ["mx_common.h", "mx_kernels.h", "mx_acc_regs.h", "mx_gemm_tile.inc", "mx_group_convert.h", "mx_instrument.h", "mx_direct_convert.h", "mx_decode_quant.h", "mx_rms_convert.h",
            os.path.join("..", "..", "include", "micromix_hip.h"), os.path.join("..", "..", "include", "micromix_diag.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 

@@ -137,6 +137,32 @@ int mm_qlinear_decode(const void *X_bf16, const int16_t *reorder_index, const ui
     return e == hipSuccess ? MM_OK : fail_hip(e, "mm_qlinear_decode");
 }
 
+int mm_rmsnorm_qlinear_decode_supported(int M, int N, int KN, int KS, int KO) {
+    if (N < 0 || KN < 0 || KS < 0 || KO < 0 || (KN % 128) || (KS % 128) || (KO % 128) || KN + KS + KO == 0 || KN + KS + KO > 32768) return 0;
+    const int K[3] = {KN, KS, KO};
+    return mm::qlinear_decode_supported(M, N, K, true);
+}
+
+int mm_rmsnorm_qlinear_decode(const void *X_bf16, const void *norm_weight_bf16, float eps, const int16_t *reorder_index, const uint8_t *BN,
+                              const uint8_t *BS, const uint8_t *BO, const uint8_t *SFBN, const uint8_t *SFBS, const uint8_t *SFBO, int M, int N,
+                              int KN, int KS, int KO, int wmode, int flags, const void *bias_bf16, void *D_bf16, mm_stream_t stream) {
+    if (M < 0 || N < 0 || KN < 0 || KS < 0 || KO < 0) return MM_ERR_BAD_ARG;
+    if ((KN % 128) || (KS % 128) || (KO % 128) || KN + KS + KO == 0) return MM_ERR_BAD_SPLIT;
+    if (wmode != MM_W_MATCH && wmode != MM_W_FP4) return MM_ERR_BAD_ARG;
+    if (flags & ~(MM_ROUND_ONCE | MM_NORM_NO_INTEGER_ROUND)) return MM_ERR_BAD_ARG;
+    if (M == 0 || N == 0) return MM_OK;
+    if (!mm_rmsnorm_qlinear_decode_supported(M, N, KN, KS, KO)) return MM_ERR_UNSUPPORTED;
+    if (!X_bf16 || !norm_weight_bf16 || !reorder_index || !D_bf16) return MM_ERR_BAD_ARG;
+    if (((uintptr_t)X_bf16 & 15) || ((uintptr_t)norm_weight_bf16 & 15)) return MM_ERR_BAD_ARG;      // rows and weights are staged in 16-byte pieces
+    if ((KN && (!BN || !SFBN)) || (KS && (!BS || !SFBS)) || (KO && (!BO || !SFBO))) return MM_ERR_BAD_ARG;
+    const uint8_t *W[3] = {BN, BS, BO}, *SFW[3] = {SFBN, SFBS, SFBO};
+    const int K[3] = {KN, KS, KO};
+    const mm::NormArgs norm = {norm_weight_bf16, eps, (flags & MM_NORM_NO_INTEGER_ROUND) ? 0 : 1};
+    hipError_t e = mm::launch_qlinear_decode(X_bf16, reorder_index, W, SFW, M, N, K, weights_fp4(wmode, KS, KO),
+                                             (flags & MM_ROUND_ONCE) ? 0 : 1, bias_bf16, D_bf16, (hipStream_t)stream, norm);
+    return e == hipSuccess ? MM_OK : fail_hip(e, "mm_rmsnorm_qlinear_decode");
+}
+
 size_t mm_matmul_workspace_bytes(int M, int N, int KN, int KS, int KO, int wmode, int flags) {
     if (M <= 0 || N <= 0 || KN < 0 || KS < 0 || KO < 0 || (KN % 128) || (KS % 128) || (KO % 128)) return 0;
     const int K[3] = {KN, KS, KO};

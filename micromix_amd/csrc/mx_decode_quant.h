@@ -4,6 +4,7 @@
 #pragma once
 #include "mx_group_convert.h"
 #include "mx_direct_convert.h"
+#include "mx_rms_convert.h"
 
 namespace mm {
 namespace dq {
@@ -18,6 +19,11 @@ struct QuantIn {
                             // alternating (mm_gate_up_activate's scratch layout), quantized as activate_quantize_x: silu(gate) * up in
                             // natural column order (activate_rows_to_lds)
     int early;              // quantize_rows_early applies: one batch (stage_rows >= M), at most one group per thread, at most EARLY_RL row loads per thread
+    // RMSNorm in front of the quantization (mm_rmsnorm_qlinear_decode; mode 0, K <= 8192): v = bf16((x * w) * rvar) with the reference's
+    // summation order and integer rounding (rmsnorm.cu:95-312) -- the bytes of mm_rmsnorm_quantize
+    const uint16_t *norm_w; // [K] bf16, or null: no norm
+    float eps;
+    int int_round;          // the reference's round() before the conversion (0: MM_RMS_NO_INTEGER_ROUND)
 };
 constexpr int EARLY_RL = 4;
 
@@ -30,6 +36,44 @@ struct LdsMap {
 __host__ __device__ inline size_t operand_bytes(int M, const int K[3]) {   // quantized rows + their scale bytes
     const size_t Kt = (size_t)K[0] + K[1] + K[2];
     return (size_t)M * (K[0] / 2 + K[1] / 4 * 3 + K[2] + Kt / 32);
+}
+// LDS behind the (16-byte rounded) operands when the norm runs inside the launch: [K bf16 norm weights | M x P partial sums | M rvar]
+__host__ __device__ inline int rms_pow2(int T) { int P = 64; while (P < T) P <<= 1; return P; }
+__host__ __device__ inline size_t rms_bytes(int M, const int K[3]) {
+    const size_t Kt = (size_t)K[0] + K[1] + K[2];
+    return Kt * 2 + (size_t)M * rms_pow2((int)(Kt >> 5)) * 4 + 64;
+}
+constexpr int RMS_MAX_K = 8192;      // the wave-local halving tree covers P <= 256 partial sums
+
+// one group with the norm: gather x and w (same byte offsets into the staged row and the staged weight vector), v = bf16((x w) rvar),
+// block exponent, the reference's integer rounding, conversion into LDS; returns the scale byte (rmsnorm_quantize.hip: rms_group)
+template <int EL>
+__device__ __forceinline__ uint32_t rms_quantize_group(const uint8_t *__restrict__ row, const uint8_t *__restrict__ wrow, const uint32_t (&ix)[16],
+                                                       float rvar, bool int_round, uint8_t *__restrict__ out) {
+    // (rms_gather of mx_rms_convert.h with the weights read where they are used: 16 registers fewer in a phase that shares its
+    // kernel with asm-owned accumulators)
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    uint32_t v[16];
+    us2 amax2 = {0, 0};
+    const f2 rvar2 = {rvar, rvar};
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const uint32_t lo = ix[i] & 0xFFFFu, hi = ix[i] >> 16;
+        const f2 x = {bf16_bits_to_f32(*reinterpret_cast<const uint16_t *>(row + lo)), bf16_bits_to_f32(*reinterpret_cast<const uint16_t *>(row + hi))};
+        const f2 w = {bf16_bits_to_f32(*reinterpret_cast<const uint16_t *>(wrow + lo)), bf16_bits_to_f32(*reinterpret_cast<const uint16_t *>(wrow + hi))};
+        const f2 r = (x * w) * rvar2;          // (x * w) is exact in fp32; one rounding in the multiply by rvar, one to bf16
+        v[i] = pack_bf16x2(r[0], r[1]);
+        const uint32_t mag = v[i] & 0x7FFF7FFFu;
+        us2 m;
+        __builtin_memcpy(&m, &mag, 4);
+        amax2 = __builtin_elementwise_max(amax2, m);
+    }
+    const uint32_t amax = amax2[0] > amax2[1] ? amax2[0] : amax2[1];
+    int e;
+    const float scale = int_round ? rms_scale<true>(v, amax, ElemTraits<EL>::FMAX_EXP, ElemTraits<EL>::FMAX_MANT, e)
+                                  : rms_scale<false>(v, amax, ElemTraits<EL>::FMAX_EXP, ElemTraits<EL>::FMAX_MANT, e);
+    convert_group<EL>(v, scale, out);
+    return (uint32_t)(e + 127);
 }
 
 // phase 1: quantize the M activation rows into LDS (reorder.cu:94-269 per group, shared quantize_group)
@@ -45,6 +89,11 @@ __device__ __forceinline__ LdsMap quantize_rows_to_lds(const QuantIn &a, uint8_t
     uint8_t *stage = smem;
     uint8_t *opN = stage + (size_t)a.stage_rows * Kt * 2, *opS = opN + a.M * pN, *opO = opS + a.M * pS;
     uint8_t *scales = opO + a.M * pO;
+    // with the norm: [norm weights | partial sums | rvar] behind the 16-byte rounded operands (rms_bytes)
+    const bool rms = a.norm_w != nullptr;
+    const int P = rms_pow2(Gt);
+    uint8_t *wvec = opN + ((operand_bytes(a.M, a.K) + 15) & ~(size_t)15);
+    float *part = reinterpret_cast<float *>(wvec + (size_t)Kt * 2), *rvar = part + (size_t)a.M * P;
 
     // ---- phase 1: quantize the M activation rows into LDS (reorder.cu:94-269 per group, shared quantize_group) ----
     // stage_rows rows are staged at a time and their (row, group) pairs are spread over all 512 threads
@@ -68,16 +117,39 @@ __device__ __forceinline__ LdsMap quantize_rows_to_lds(const QuantIn &a, uint8_t
         if (t0 < nr * Gt) load_ix(t0 % Gt, ix);
         const uint4 *grow = reinterpret_cast<const uint4 *>(a.X + (size_t)r0 * Kt);
         for (int c = threadIdx.x; c < nr * (Kt >> 3); c += NT) reinterpret_cast<uint4 *>(stage)[c] = grow[c];
+        if (rms && r0 == 0)
+            for (int c = threadIdx.x; c < (Kt >> 3); c += NT) reinterpret_cast<uint4 *>(wvec)[c] = reinterpret_cast<const uint4 *>(a.norm_w)[c];
         __syncthreads();
         if (r0 == 0) staged();
+        if (rms) {
+            // the reference's sum of squares per row: Gt group threads' partial sums (zero padded to P), then the halving tree, one wave per row
+            for (int u = threadIdx.x; u < nr * P; u += NT) {
+                const int rr = u / P, t = u - rr * P;
+                const uint4 *row4 = reinterpret_cast<const uint4 *>(stage + (size_t)rr * Kt * 2);
+                part[u] = t < Gt ? rms_thread_sum(t, Gt, [&](int q) { return row4[q]; }) : 0.0f;
+            }
+            __syncthreads();
+            for (int rr = threadIdx.x >> 6; rr < nr; rr += NT / 64) {
+                const float rv = rms_tree_rvar(part + rr * P, P, threadIdx.x & 63, Kt, a.eps);
+                if ((threadIdx.x & 63) == 0) rvar[r0 + rr] = rv;
+            }
+            __syncthreads();
+        }
         for (int t = t0; t < nr * Gt; t += NT) {
             const int rr = t / Gt, g = t - rr * Gt, r = r0 + rr;
             const uint8_t *row = stage + (size_t)rr * Kt * 2;
             if (t != t0) load_ix(g, ix);
             uint32_t byte;
-            if (g < gN) byte = quantize_group<EL_FP4>(row, ix, opN + r * pN + g * 16);
-            else if (g < gN + gS) byte = quantize_group<EL_FP6>(row, ix, opS + r * pS + (g - gN) * 24);
-            else byte = quantize_group<EL_FP8>(row, ix, opO + r * pO + (g - gN - gS) * 32);
+            if (rms) {
+                const float rv = rvar[r];
+                if (g < gN) byte = rms_quantize_group<EL_FP4>(row, wvec, ix, rv, a.int_round != 0, opN + r * pN + g * 16);
+                else if (g < gN + gS) byte = rms_quantize_group<EL_FP6>(row, wvec, ix, rv, a.int_round != 0, opS + r * pS + (g - gN) * 24);
+                else byte = rms_quantize_group<EL_FP8>(row, wvec, ix, rv, a.int_round != 0, opO + r * pO + (g - gN - gS) * 32);
+            } else {
+                if (g < gN) byte = quantize_group<EL_FP4>(row, ix, opN + r * pN + g * 16);
+                else if (g < gN + gS) byte = quantize_group<EL_FP6>(row, ix, opS + r * pS + (g - gN) * 24);
+                else byte = quantize_group<EL_FP8>(row, ix, opO + r * pO + (g - gN - gS) * 32);
+            }
             scales[r * Gt + g] = (uint8_t)byte;
         }
         __syncthreads();

@@ -100,7 +100,6 @@ namespace mm {
 #undef MM_WM
 #undef MM_TM
 #undef MM_TN
-#undef MM_W1
 #undef MM_ACC
 #undef MM_MAX_STAGES
 #undef MM_LDS_BUDGET

@@ -257,7 +257,6 @@ __device__ __forceinline__ void stream_body(const GemmArgs &a, const dq::QuantIn
     const int rd8a = (li >> 3) * 1024 + (8 * (li & 7) + (h ^ s8)) * 16, rd8b = (li >> 3) * 1024 + (8 * (li & 7) + ((4 + h) ^ s8)) * 16;
 
     static_assert(12 * ACC <= 192, "a[0:191]");
-    static_for<12 * ACC>([&](auto r_) { acc_zero<decltype(r_)::value, 12 * ACC>(); });
 
     // slab s of segment G into slot d: RG::LOADS vector-memory instructions, whatever the segment
     auto issue_g = [&](Slot &q, int d, auto G_, int s) {
@@ -381,6 +380,9 @@ __device__ __forceinline__ void stream_body(const GemmArgs &a, const dq::QuantIn
     } else {
         prime();
     }
+    // the accumulators are cleared HERE, behind the quantization phase: nothing asm-owned is live while the compiler allocates that
+    // phase's registers (with the norm inside it once parked values in a[2:3]; the build guard caught it)
+    static_for<12 * ACC>([&](auto r_) { acc_zero<decltype(r_)::value, 12 * ACC>(); });
     if (cnt > 0) {
         MM_STAMP(1);
         for (int r = 0; r + 1 < rounds; ++r) {
@@ -553,7 +555,8 @@ static hipError_t launch_quant(const GemmArgs &a, dq::QuantIn qi, hipStream_t st
     const int present = (a.K[0] ? 1 : 0) + (a.K[1] ? 1 : 0) + (a.K[2] ? 1 : 0);
     const size_t red_bytes = (size_t)NW * present * F * 4 * 64 * sizeof(float), ring_bytes = (size_t)NW * D * Ring<F, 1, W4, true>::SLOT;
     const size_t tail = red_bytes > ring_bytes ? red_bytes : ring_bytes;
-    const size_t Kt = (size_t)a.K[0] + a.K[1] + a.K[2], ops = (dq::operand_bytes(a.M, a.K) + 15) & ~(size_t)15;
+    const size_t Kt = (size_t)a.K[0] + a.K[1] + a.K[2];
+    const size_t ops = ((dq::operand_bytes(a.M, a.K) + 15) & ~(size_t)15) + (qi.norm_w != nullptr ? dq::rms_bytes(a.M, a.K) : 0);
     // staged bf16 rows: all M if two workgroups still fit a CU's 160 KB, else as many as one workgroup can hold (at least one)
     constexpr size_t LDS_CU = 160 * 1024, LDS_WG = 156 * 1024;
     size_t rows = qi.mode == 1 ? 0 : a.M;       // (mode 1 quantizes straight from global memory: nothing is staged)
@@ -567,7 +570,7 @@ static hipError_t launch_quant(const GemmArgs &a, dq::QuantIn qi, hipStream_t st
     qi.stage_rows = (int)rows;
     qi.early = (qi.mode != 1 && rows >= (size_t)a.M && (size_t)a.M * (Kt / 32) <= 64u * NW && (size_t)a.M * (Kt / 8) <= 64u * NW * dq::EARLY_RL) ? 1 : 0;
     static const int early_on = getenv("MICROMIX_DECODE_EARLY") ? atoi(getenv("MICROMIX_DECODE_EARLY")) : 1;   // kernel-developer override
-    if (!early_on) qi.early = 0;
+    if (!early_on || qi.norm_w != nullptr) qi.early = 0;      // (the norm runs in the generic phase: its partial sums need the staged rows first)
     const size_t qbytes = rows * Kt * 2 + ops, lds = qbytes + tail;
     if (lds > LDS_WG) return hipErrorInvalidValue;      // (every mode: the supported() predicates keep callers away from this)
     static DynamicLdsOnce once;
@@ -625,25 +628,31 @@ bool mx_gemm_stream_supported(int M, int N, const int K[3], bool w4) {
 constexpr size_t STREAM_TAIL_BUDGET = 64 * 1024;
 
 // 1 if mm_qlinear_decode can run on the streaming kernel (the quantized rows, one staged row and the rings fit a workgroup's LDS)
-bool qlinear_stream_supported(int M, int N, const int K[3]) {
+bool qlinear_stream_supported(int M, int N, const int K[3], bool rms) {
     static const int on = getenv("MICROMIX_DECODE_STREAM") ? atoi(getenv("MICROMIX_DECODE_STREAM")) : 1;   // kernel-developer override
     // Measured against the first fused kernel (qlinear_decode.hip; tools/time_decode.py, profiles/r04_stream_ablation.txt section 8):
     // it wins where N / 32 fills the CUs and one pass quantizes the rows (gate/up at M = 1 / 2 / 4: 12.5 / 11.8 / 14.3 -> 10.2 / 9.2 /
     // 12.3 us) and loses on q/k/v/o (few workgroups: all start-up) and at M = 8 (two passes per workgroup: quantize + GEMM wins there).
     const size_t Kt = (size_t)K[0] + K[1] + K[2];
-    if (on == 2 && M >= 1 && M <= 8) return dq::operand_bytes(M, K) + Kt * 2 + STREAM_TAIL_BUDGET + 64 <= 156 * 1024;     // (A/B runs: every shape that fits)
+    const size_t norm = rms ? dq::rms_bytes(M, K) : 0;
+    if (rms && Kt > (size_t)dq::RMS_MAX_K) return false;
+    if (on == 2 && M >= 1 && M <= 8) return dq::operand_bytes(M, K) + norm + Kt * 2 + STREAM_TAIL_BUDGET + 64 <= 156 * 1024;     // (A/B runs: every shape that fits)
     if (!on || M < 1 || M > 4 || (N + 31) / 32 < device_cus()) return false;
-    return dq::operand_bytes(M, K) + Kt * 2 + STREAM_TAIL_BUDGET + 64 <= 156 * 1024;
+    return dq::operand_bytes(M, K) + norm + Kt * 2 + STREAM_TAIL_BUDGET + 64 <= 156 * 1024;
 }
 
 hipError_t launch_qlinear_stream(const void *X, const int16_t *idx, const uint8_t *const W[3], const uint8_t *const SFW[3], int M, int N,
-                                 const int K[3], bool w4, int round_per_segment, const void *bias, void *D, hipStream_t stream) {
+                                 const int K[3], bool w4, int round_per_segment, const void *bias, void *D, hipStream_t stream,
+                                 const NormArgs &norm) {
     using namespace stream;
     GemmArgs a = {};
     dq::QuantIn qi = {};
     qi.X = (const uint16_t *)X;
     qi.idx = idx;
     qi.M = M;
+    qi.norm_w = (const uint16_t *)norm.weight;
+    qi.eps = norm.eps;
+    qi.int_round = norm.int_round;
     for (int g = 0; g < 3; ++g) {
         a.W[g] = W[g];
         a.SFW[g] = SFW[g];

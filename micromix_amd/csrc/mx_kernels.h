@@ -142,10 +142,13 @@ hipError_t launch_direct_quantize(const void *A, const void *B, int rows, int KN
 hipError_t launch_rmsnorm_quantize(const void *src, const void *weight, float eps, int rows, int K, const int16_t *idx, int KN,
                                    int KS, int KO, bool integer_round, uint8_t *oN, uint8_t *oS, uint8_t *oO, uint8_t *sfN,
                                    uint8_t *sfS, uint8_t *sfO, hipStream_t stream);
-int qlinear_decode_supported(int M, int N, const int K[3]);
+// RMSNorm in front of the quantization of the decode launches (mm_rmsnorm_qlinear_decode): weight == nullptr means no norm
+struct NormArgs { const void *weight; float eps; int int_round; };
+constexpr NormArgs NO_NORM = {nullptr, 0.0f, 1};
+int qlinear_decode_supported(int M, int N, const int K[3], bool rms = false);
 hipError_t launch_qlinear_decode(const void *X, const int16_t *idx, const uint8_t *const W[3], const uint8_t *const SFW[3],
                                  int M, int N, const int K[3], bool w4, int round_per_segment, const void *bias, void *D,
-                                 hipStream_t stream);
+                                 hipStream_t stream, const NormArgs &norm = NO_NORM);
 hipError_t launch_mx_gemm(const GemmArgs &a, bool w4, hipStream_t stream);
 hipError_t launch_mx_gemm256(const GemmArgs &a, bool w4, hipStream_t stream);
 bool mx_gemm_act_supported(int M, int N);                                 // the tiled kernels with the fused gate / up epilogue take this shape
@@ -162,9 +165,10 @@ bool down_activate_stream_supported(int M, int N, const int K[3]);
 hipError_t launch_down_activate_stream(const void *GU, const uint8_t *const W[3], const uint8_t *const SFW[3], int M, int N, const int K[3],
                                        bool w4, int round_per_segment, const void *bias, void *D, hipStream_t stream);
 // ... with the quantization of the M <= 8 activation rows inside every workgroup (mm_qlinear_decode)
-bool qlinear_stream_supported(int M, int N, const int K[3]);
+bool qlinear_stream_supported(int M, int N, const int K[3], bool rms = false);
 hipError_t launch_qlinear_stream(const void *X, const int16_t *idx, const uint8_t *const W[3], const uint8_t *const SFW[3], int M, int N,
-                                 const int K[3], bool w4, int round_per_segment, const void *bias, void *D, hipStream_t stream);
+                                 const int K[3], bool w4, int round_per_segment, const void *bias, void *D, hipStream_t stream,
+                                 const NormArgs &norm = NO_NORM);
 hipError_t launch_mx_gemm_skinny_grouped(const GroupedGemmArgs &ga, int max_m, bool w4, hipStream_t stream);
 size_t mx_gemm_workspace_bytes(int M, int N, const int K[3], bool w4, bool force, bool tickets_zeroed);
 bool mx_gemm_small_m_uses_tiles(int M, int N, const int K[3], bool w4, size_t ws_bytes, bool force_split);

@@ -88,6 +88,9 @@ struct Args {
     const uint16_t *bias;
     uint16_t *D;
     int stage_rows;         // activation rows staged in LDS at a time (launcher: as many as fit)
+    const uint16_t *norm_w; // RMSNorm in front of the quantization (null: none), see dq::QuantIn
+    float eps;
+    int int_round;
 };
 
 // this wave's slabs of one segment; xl = LDS base of the segment's quantized rows (pitch xp bytes), sl = LDS base of the
@@ -149,6 +152,8 @@ __device__ __forceinline__ LdsMap quantize_rows_to_lds(const Args &a, uint8_t *s
     dq::QuantIn q;
     q.X = a.X; q.idx = a.idx; q.M = a.M; q.stage_rows = a.stage_rows;
     q.K[0] = a.K[0]; q.K[1] = a.K[1]; q.K[2] = a.K[2];
+    q.mode = 0; q.early = 0;
+    q.norm_w = a.norm_w; q.eps = a.eps; q.int_round = a.int_round;
     return dq::quantize_rows_to_lds<NT>(q, smem);
 }
 
@@ -350,7 +355,9 @@ __global__ void __launch_bounds__(NT) qlinear_decode16_kernel(Args a) {
 
 // dynamic LDS: the quantized rows and scales of all M rows + as many staged bf16 rows as fit next to the 32 KB reduction buffer
 constexpr size_t DECODE_LDS_MAX = 126 * 1024;
-static size_t decode_operand_bytes(int M, const int K[3]) { return dq::operand_bytes(M, K); }
+static size_t decode_operand_bytes(int M, const int K[3], bool rms = false) {
+    return rms ? ((dq::operand_bytes(M, K) + 15) & ~(size_t)15) + dq::rms_bytes(M, K) : dq::operand_bytes(M, K);
+}
 
 // features per workgroup: 16 while 32 would leave half of the CUs without a workgroup
 static int decode_features(int N) { return 2 * ((N + 31) / 32) <= device_cus() ? 16 : 32; }
@@ -358,13 +365,14 @@ static int decode_features(int N) { return 2 * ((N + 31) / 32) <= device_cus() ?
 // 0: cannot run; 1: can run; 2: can run and is expected to beat quantize + GEMM.  Every workgroup repeats the quantization, in
 // ceil(M * K/32 / 512) passes of ~1.4 us, and the workgroups take ceil(N/features / CUs) rounds; measured on MI355X the fused
 // kernel wins while rounds * passes <= 2 (q/o up to M = 8, gate/up and down up to M = 2-4) and loses beyond.
-int qlinear_decode_supported(int M, int N, const int K[3]) {
+int qlinear_decode_supported(int M, int N, const int K[3], bool rms) {
     const size_t Kt = (size_t)K[0] + K[1] + K[2];
-    if (M < 1 || M > 8 || Kt * 2 + decode_operand_bytes(M, K) > DECODE_LDS_MAX) return 0;   // at least one staged row must fit
+    if (rms && Kt > (size_t)dq::RMS_MAX_K) return 0;
+    if (M < 1 || M > 8 || Kt * 2 + decode_operand_bytes(M, K, rms) > DECODE_LDS_MAX) return 0;   // at least one staged row must fit
     // layers wide enough for the streaming kernel's workgroup-local quantization (mx_gemm_stream.hip): it beats quantize + GEMM at
     // M = 1 and 2 (gate/up 10.6-12.7 -> 8.5-9.3 us, fused gate + up 18.3-19.0 -> 16.2-17.7) and ties or loses from M = 4 on
     // (every workgroup repeats the quantization: beyond ~4 rounds of workgroups -- not measured, N > 32768 -- one separate quantize launch is cheaper)
-    if (qlinear_stream_supported(M, N, K)) return (M <= 2 && N <= 32768) ? 2 : 1;
+    if (qlinear_stream_supported(M, N, K, rms)) return (M <= 2 && N <= 32768) ? 2 : 1;
     const int feat = decode_features(N), cus = device_cus();
     const int rounds = ((N + feat - 1) / feat + cus - 1) / cus;
     const int passes = (int)((M * (Kt / 32) + decode::NT - 1) / decode::NT);
@@ -373,10 +381,14 @@ int qlinear_decode_supported(int M, int N, const int K[3]) {
 
 hipError_t launch_qlinear_decode(const void *X, const int16_t *idx, const uint8_t *const W[3], const uint8_t *const SFW[3],
                                  int M, int N, const int K[3], bool w4, int round_per_segment, const void *bias, void *D,
-                                 hipStream_t stream) {
+                                 hipStream_t stream, const NormArgs &norm) {
     using namespace decode;
-    if (qlinear_stream_supported(M, N, K)) return launch_qlinear_stream(X, idx, W, SFW, M, N, K, w4, round_per_segment, bias, D, stream);
+    const bool rms = norm.weight != nullptr;
+    if (qlinear_stream_supported(M, N, K, rms)) return launch_qlinear_stream(X, idx, W, SFW, M, N, K, w4, round_per_segment, bias, D, stream, norm);
     Args a;
+    a.norm_w = (const uint16_t *)norm.weight;
+    a.eps = norm.eps;
+    a.int_round = norm.int_round;
     a.X = (const uint16_t *)X;
     a.idx = idx;
     for (int i = 0; i < 3; ++i) {
@@ -390,7 +402,7 @@ hipError_t launch_qlinear_decode(const void *X, const int16_t *idx, const uint8_
     a.round_per_segment = round_per_segment;
     a.bias = (const uint16_t *)bias;
     a.D = (uint16_t *)D;
-    const size_t Kt = (size_t)K[0] + K[1] + K[2], ops = decode_operand_bytes(M, K);
+    const size_t Kt = (size_t)K[0] + K[1] + K[2], ops = decode_operand_bytes(M, K, rms);
     int stage_rows = (int)((DECODE_LDS_MAX - ops) / (Kt * 2));
     stage_rows = stage_rows > M ? M : stage_rows;
     a.stage_rows = stage_rows;

@@ -25,73 +25,14 @@
 //   wave sums the partial sums by itself after ONE barrier (same tree, same order): two barriers per row instead of four.
 //   K > 8192 (rmsnorm_quantize_kernel): the 16-bit row and 32 gathered norm weights per thread in registers (the 32-bit row
 //   of K = 32768 would not fit the LDS).
+#include <stdlib.h>
+
 #include "mx_group_convert.h"
+#include "mx_rms_convert.h"
 #include "mx_kernels.h"
 
 namespace mm {
 
-// One group in three steps, the first two the same for every element format, so that a wave whose lanes sit in different
-// segments runs them once (only the conversion diverges):
-//   rms_gather: v = bf16((x * w) * rvar) for the group's 32 columns, returns the absmax's bf16 magnitude bits.
-//     PRODUCTS: `row` holds fp32 products x * w at the byte offsets in `ix` (wg unused); else bf16 x at `ix` and the weights in wg
-template <bool PRODUCTS>
-__device__ __forceinline__ uint32_t rms_gather(const uint8_t *__restrict__ row, const uint32_t (&ix)[16], const uint32_t (&wg)[16],
-                                               float rvar, uint32_t (&v)[16]) {
-    typedef float f2 __attribute__((ext_vector_type(2)));   // two-wide fp32 arithmetic (v_pk_mul_f32 / v_pk_add_f32)
-    us2 amax2 = {0, 0};
-    const f2 rvar2 = {rvar, rvar};
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        f2 xw;
-        if constexpr (PRODUCTS) {
-            xw = f2{*reinterpret_cast<const float *>(row + (ix[i] & 0xFFFFu)), *reinterpret_cast<const float *>(row + (ix[i] >> 16))};
-        } else {
-            const f2 x = {bf16_bits_to_f32(*reinterpret_cast<const uint16_t *>(row + (ix[i] & 0xFFFFu))),
-                          bf16_bits_to_f32(*reinterpret_cast<const uint16_t *>(row + (ix[i] >> 16)))};
-            const f2 w = {bf16_bits_to_f32(wg[i] & 0xFFFFu), bf16_bits_to_f32(wg[i] >> 16)};
-            xw = x * w;
-        }
-        // (x * w) is exact in fp32 (two 8-bit significands); one rounding in the multiply by rvar, one to bf16
-        const f2 r = xw * rvar2;
-        v[i] = pack_bf16x2(r[0], r[1]);
-        const uint32_t mag = v[i] & 0x7FFF7FFFu;
-        us2 m;
-        __builtin_memcpy(&m, &mag, 4);
-        amax2 = __builtin_elementwise_max(amax2, m);
-    }
-    return amax2[0] > amax2[1] ? amax2[0] : amax2[1];
-}
-//   rms_scale: the block's exponent e for the lane's format (FMAX given by fexp / fmant); with INT_ROUND v becomes
-//     round(v * 2^-e), half away from zero, and the conversion's scale 1; returns the scale pattern for convert_group.
-//     (e = -127, a block below FMAX * 2^-127, is no special case: 2^127 * (1 + 2^-10) is a normal fp32, and the converters read the
-//     scale pattern 0 as 2^-127 -- see convert_group.)
-template <bool INT_ROUND>
-__device__ __forceinline__ float rms_scale(uint32_t (&v)[16], uint32_t amax, int fexp, uint32_t fmant, int &e) {
-    typedef float f2 __attribute__((ext_vector_type(2)));
-    e = scale_exponent_rt(amax << 16, fexp, fmant);
-    if constexpr (INT_ROUND) {
-        // t = v * 2^-e is exact and has 8 significant bits, so t * (1 + 2^-10) is exact in fp32 too, lies strictly between t and the
-        // next point an 8-bit value could occupy, and is never a tie: rounding IT to nearest-even (v_rndne_f32) is rounding t half
-        // away from zero (a tie k + 0.5 moves off the tie, away from zero; a non-tie is at least one 8-bit step from the nearest
-        // tie, four times the nudge).  |t| >= 128 is an integer already and the nudge stays below 0.5.  The reference's clamp to
-        // +-FMAX cannot bite: e is the smallest exponent with FMAX * 2^e >= amax, so |t| <= FMAX, an integer.
-        // (Was trunc(t + copysign(0.5, t)): 9 VALU operations per pair, now 6.)
-        // (e <= 126 for every finite bf16 absmax: FMAX * 2^126 >= 1.5 * 2^128 is beyond the format; only an inf / NaN block reaches
-        // e = 127, whose exponent field would be 0 here -- a denormal multiplier -- so the multiplier's exponent is capped: such a
-        // block stays inf / NaN through the conversion either way)
-        const int em = e > 126 ? 126 : e;
-        const float rs = __uint_as_float(((uint32_t)(127 - em) << 23) | 0x2000u);  // 2^-e * (1 + 2^-10)
-        const f2 rs2 = {rs, rs};
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const f2 t = f2{bf16_bits_to_f32(v[i] & 0xFFFFu), bf16_bits_to_f32(v[i] >> 16)} * rs2;
-            v[i] = pack_bf16x2(__builtin_rintf(t[0]), __builtin_rintf(t[1]));
-        }
-        return 1.0f;
-    } else {
-        return __uint_as_float((uint32_t)(127 + e) << 23);
-    }
-}
 //   then convert_group<EL> into global memory (fp4: 16 bytes per lane, whole lines as they are) or into the LDS image of the row's
 //   fp6 / fp8 codes (store_code_image, mx_group_convert.h).
 template <bool INT_ROUND, bool PRODUCTS>
@@ -343,6 +284,201 @@ rmsnorm_quantize_products_kernel(const uint16_t *__restrict__ src, const uint16_
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// K <= 8192, round 5: the rows arrive by LDS-DMA in a ring of R slots (rmsnorm_quantize_ring_kernel).
+// Why: the products kernel above keeps 167 VGPRs (six workgroups of two waves per CU) and one 8 KB row in flight per workgroup:
+// ~48 KB of loads in flight per CU, where reorder_quantize_kernel -- the same bytes, 0.72 of 8 TB/s -- has 13-16 workgroups' rows in
+// flight.  Here a row costs no registers while it travels: `buffer_load_dwordx4 ... lds` (four 1 KB pieces per wave and row, the
+// chunk swizzle of mx_group_convert.h applied on the SOURCE address) straight into slot r % R, R - 1 rows ahead, behind ONE counted
+// s_waitcnt vmcnt.  The row stays bf16 (8 KB per slot at K = 4096); the norm weights of the thread's 32 columns are gathered once
+// into 16 registers (as in rmsnorm_quantize_kernel); the sum of squares reads the thread's four chunks back from LDS in the
+// reference's order; every wave walks the halving tree by itself.  Two barriers per row:
+//   B1(r): row r has landed for every wave AND every wave is done with row r-1 (its slot is refilled right behind B1: row r+R-1);
+//          the [S | O] code image of row r-1 is complete: it leaves here (store_code_image);
+//   B2(r): the T partial sums are in LDS.
+// vmcnt counts loads, stores and LDS-DMA together in issue order.  Per iteration a wave issues: [wait] B1, the image stores of row
+// r-1 (0-2), the four DMAs of row r+R-1, B2, then the stores of row r: the scale dword (always: lane 0 of every wave owns one) and the
+// fp4 codes (when the wave has a lane in the fp4 segment).  So younger than row r's own DMAs are, per ring step, at least 4 DMAs + 1
+// store: vmcnt(5 (R - 2)) never lets one of row r's pieces stay in flight, and lets the rows behind it (all of them but at most one
+// piece per step, when a wave issues both stores) travel on.  When the next row does not exist nothing was issued for it: vmcnt(0).
+// Every wave issues exactly four DMAs per row (rows of K <= 8192 are at most 16 pieces on at most 4 waves); a piece past the row's
+// end lies past the descriptor's range, fetches nothing and lands in a dump area of its own.
+// ---------------------------------------------------------------------------------------------------------
+typedef int rms_rsrc_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ rms_rsrc_t rms_make_rsrc(const void *base, unsigned bytes) {
+    const unsigned long long v = (unsigned long long)base;
+    rms_rsrc_t r;
+    r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)v);
+    r[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(v >> 32) & 0xFFFFu));
+    r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+    r[3] = 0x00020000;
+    return r;
+}
+// one buffer_load_dwordx4 ... lds: 64 lanes x 16 B -> LDS bytes [lds, lds + 1024) in lane order (M0 = wave-uniform base; the compiler
+// owns M0, so it is saved and restored; s_nop 4 / 0: SALU -> VMEM and M0 -> LDS-DMA wait states)
+__device__ __forceinline__ void rms_dma16(const rms_rsrc_t &rsrc, int voff, int soff, unsigned lds) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    unsigned keep;
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                 "buffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(rsrc), "s"(lds), "s"(soff)
+                 : "memory");
+#endif
+}
+template <int N>
+__device__ __forceinline__ void rms_wait_vmcnt() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+#endif
+}
+
+template <bool INT_ROUND, int R>
+__global__ void __launch_bounds__(256)
+rmsnorm_quantize_ring_kernel(const uint16_t *__restrict__ src, const uint16_t *__restrict__ weight, float eps, int rows, int K,
+                             const int16_t *__restrict__ idx, int KN, int KS, int KO, uint8_t *__restrict__ oN,
+                             uint8_t *__restrict__ oS, uint8_t *__restrict__ oO, uint8_t *__restrict__ sfN,
+                             uint8_t *__restrict__ sfS, uint8_t *__restrict__ sfO, int slot_bytes) {
+    static_assert(R >= 3 && 5 * (R - 2) < 64, "ring depth");
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];   // [R slots][1 KB dump][P floats of partial sums][image of the S | O codes]
+    const int T = K >> 5;
+    const int g = threadIdx.x;
+    const bool active = g < T;
+    const int wave = __builtin_amdgcn_readfirstlane(g >> 6), lane = g & 63, nw = (int)blockDim.x >> 6;
+    uint8_t *const dump = smem + (size_t)R * slot_bytes;
+    float *part = reinterpret_cast<float *>(dump + 1024);
+    int P = 64;
+    while (P < T) P <<= 1;
+    const int bytesS = KS / 4 * 3;
+    uint8_t *image = reinterpret_cast<uint8_t *>(part) + (size_t)(P > (int)blockDim.x ? P : (int)blockDim.x) * 4;
+    const unsigned lds0 = (unsigned)(unsigned long long)smem;
+    const int pieces = (K + 511) >> 9;                       // 1 KB pieces of a row
+    // this lane's source offset inside a piece: LDS chunk c = 64 i + p holds source chunk swizzle_chunk(c) = 64 i + swizzle_chunk(p)
+    const int voff = swizzle_chunk(lane) * 16;
+
+    // rows r0, r0 + stride, ...: DMA of the n-th of them into slot n % R
+    const int stride = (int)gridDim.x;
+    auto issue_row = [&](int r, int slot) {
+        const rms_rsrc_t rs = rms_make_rsrc(src + (size_t)r * K, (unsigned)K * 2u);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int pc = wave + i * nw;                    // piece index (wave-uniform); past the row: nothing fetched, lands in the dump
+            const bool real = pc < pieces;
+            rms_dma16(rs, real ? voff : 0x7FFFFF00, __builtin_amdgcn_readfirstlane(real ? pc * 1024 : 0),
+                      __builtin_amdgcn_readfirstlane(real ? lds0 + (unsigned)slot * (unsigned)slot_bytes + (unsigned)pc * 1024u
+                                                          : lds0 + (unsigned)R * (unsigned)slot_bytes));
+        }
+    };
+
+    // ---- prologue: the thread's 32 column offsets and norm weights.  The weight vector is staged in the LAST slot (free until the
+    // first refill, behind B1 of the first row) by plain loads; the first R - 1 rows are requested behind those loads ----
+    uint32_t ix[16], wg[16];
+    uint8_t *const wslot = smem + (size_t)(R - 1) * slot_bytes;
+    // The index and weight loads are issued from inline asm (the compiler would wait for them where it first touches them -- before the
+    // DMAs are even requested), the first R - 1 rows follow at once, and ONE counted wait certifies the plain loads: they are older
+    // than the `dmas` LDS-DMA instructions behind them.
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    v4u wq[4] = {}, iq[4] = {};
+    {
+        [[maybe_unused]] const uint4 *ip = reinterpret_cast<const uint4 *>(idx + (size_t)(active ? g : 0) * 32), *wp = reinterpret_cast<const uint4 *>(weight);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(iq[i]) : "v"(ip + i) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(wq[i]) : "v"(wp + (active ? i * T + g : 0)) : "memory");
+#endif
+        }
+    }
+    int r = (int)blockIdx.x;
+    int dmas = 0;
+#pragma unroll
+    for (int n = 0; n < R - 1; ++n)
+        if (r + n * stride < rows) { issue_row(r + n * stride, n); dmas += 4; }
+    if (dmas >= 12) rms_wait_vmcnt<12>();
+    else if (dmas == 8) rms_wait_vmcnt<8>();
+    else if (dmas == 4) rms_wait_vmcnt<4>();
+    else rms_wait_vmcnt<0>();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+v"(iq[i]), "+v"(wq[i]));     // valid from here on
+#endif
+    }
+    if (active) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) reinterpret_cast<v4u *>(wslot)[swizzle_chunk(i * T + g)] = wq[i];
+    }
+    __syncthreads();        // the staged weights are visible
+    if (active) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t w[4] = {iq[i][0], iq[i][1], iq[i][2], iq[i][3]};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t both = swizzle_offsets((w[k] << 1) & 0xFFFEFFFEu);       // byte offsets into a staged (chunk-swizzled) [K] bf16 vector
+                const uint32_t b0 = both & 0xFFFFu, b1 = both >> 16;
+                ix[4 * i + k] = both;
+                wg[4 * i + k] = (uint32_t)*reinterpret_cast<const uint16_t *>(wslot + b0) |
+                                ((uint32_t)*reinterpret_cast<const uint16_t *>(wslot + b1) << 16);
+            }
+        }
+    }
+    const int gN = KN >> 5, gS = KS >> 5;
+    int seg, j, kseg;
+    if (g < gN) { seg = 0; j = g; kseg = KN; }
+    else if (g < gN + gS) { seg = 1; j = g - gN; kseg = KS; }
+    else { seg = 2; j = g - gN - gS; kseg = KO; }
+
+    int slot = 0, prev = -1;
+    for (int it = 0; r < rows; r += stride, ++it) {
+        // row r has landed (this wave's pieces; the barrier extends it to every wave's)
+        // (the first R - 1 iterations: the rows requested by the prologue have no stores between them -- only the DMAs are counted)
+        if (r + (R - 2) * stride >= rows) rms_wait_vmcnt<0>();
+        else if (it < R - 1) rms_wait_vmcnt<4 * (R - 2)>();
+        else rms_wait_vmcnt<5 * (R - 2)>();
+        __syncthreads();                                                                  // B1
+        if (prev >= 0) store_code_image(image, bytesS, KO, oS, oO, prev);                 // the previous row's fp6 / fp8 codes leave
+        {
+            const int rn = r + (R - 1) * stride;
+            int sn = slot + (R - 1);
+            sn = sn >= R ? sn - R : sn;
+            if (rn < rows) issue_row(rn, sn);                                             // into the slot the previous row has left
+        }
+        const uint8_t *row = smem + (size_t)slot * slot_bytes;
+        float sum = 0.0f;
+        if (active) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint4 q = reinterpret_cast<const uint4 *>(row)[swizzle_chunk(i * T + g)];
+                const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float a = bf16_bits_to_f32(w[k] & 0xFFFFu), b = bf16_bits_to_f32(w[k] >> 16);
+                    sum = __builtin_fmaf(a, a, sum);  // a*a is exact: the fused and the unfused forms round identically
+                    sum = __builtin_fmaf(b, b, sum);
+                }
+            }
+        }
+        part[g] = sum;              // threads T.. contribute the zero padding (P < 2 * blockDim.x)
+        if (g + (int)blockDim.x < P) part[g + blockDim.x] = 0.0f;
+        __syncthreads();                                                                  // B2
+        const float rvar = rms_tree_rvar(part, P, lane, K, eps);
+        if (active) {
+            const uint32_t byte = rms_group<INT_ROUND, false>(row, ix, wg, rvar, seg, j, r, KN, oN, image, bytesS);
+            uint8_t *sf = seg == 0 ? sfN : seg == 1 ? sfS : sfO;
+            const uint32_t b1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)byte, 0x55, 0xF, 0xF, false);
+            const uint32_t b2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)byte, 0xAA, 0xF, 0xF, false);
+            const uint32_t b3 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)byte, 0xFF, 0xF, 0xF, false);
+            if ((g & 3) == 0)
+                store_scale_dword(sf + sf_offset(r, j, kseg), byte | (b1 << 8) | (b2 << 16) | (b3 << 24));
+        }
+        prev = r;
+        slot = slot + 1 == R ? 0 : slot + 1;
+    }
+    __syncthreads();
+    if (prev >= 0) store_code_image(image, bytesS, KO, oS, oO, prev);
+}
+
 hipError_t launch_rmsnorm_quantize(const void *src, const void *weight, float eps, int rows, int K, const int16_t *idx, int KN,
                                    int KS, int KO, bool integer_round, uint8_t *oN, uint8_t *oS, uint8_t *oO, uint8_t *sfN,
                                    uint8_t *sfS, uint8_t *sfO, hipStream_t stream) {
@@ -352,6 +488,30 @@ hipError_t launch_rmsnorm_quantize(const void *src, const void *weight, float ep
     int P = 64;
     while (P < T) P <<= 1;
     const bool products = threads <= 256;   // K <= 8192: the 32-bit product row (see the header)
+    // K <= 8192, round 5: the LDS-DMA row ring (MICROMIX_RMS_RING=0: the products kernel; =3 / 4: ring depth)
+    // Measured (round 5, tools/time_rmsnorm.py, K = 4096, us, products / ring of 3): 256 rows 7.5 / 5.8 -- the ring kernel's prologue
+    // requests its first rows before anything else -- but 4096 rows 11.6 / 14.7: with several rows per workgroup the launch is bound by
+    // the per-row instruction stream (the integer rounding alone is 1.5 us of it), not by bytes in flight, and the ring kernel reads its
+    // row back from LDS for the sum of squares.  So: the ring while a workgroup sees at most ~2 rows (rows <= 2 x CUs), the products
+    // kernel beyond.  MICROMIX_RMS_RING=0 never, =3 / =4 always with that depth.
+    static const int ring_pin = getenv("MICROMIX_RMS_RING") ? atoi(getenv("MICROMIX_RMS_RING")) : -1;
+    const int ring = ring_pin >= 0 ? ring_pin : (rows <= 2 * device_cus() ? 3 : 0);
+    if (products && ring >= 3) {
+        const int slot = ((K * 2 + 1023) / 1024) * 1024;
+        const int R = ring >= 4 ? 4 : 3;
+        const size_t lds_r = (size_t)R * slot + 1024 + (size_t)(P > threads ? P : threads) * 4 + (size_t)KS / 4 * 3 + KO;
+        auto kr = R == 4 ? (integer_round ? rmsnorm_quantize_ring_kernel<true, 4> : rmsnorm_quantize_ring_kernel<false, 4>)
+                         : (integer_round ? rmsnorm_quantize_ring_kernel<true, 3> : rmsnorm_quantize_ring_kernel<false, 3>);
+        static DynamicLdsOnce rattr[4];
+        if (lds_r > 48 * 1024)
+            if (hipError_t e = rattr[(R == 4 ? 2 : 0) + (integer_round ? 1 : 0)].ensure(reinterpret_cast<const void *>(kr), 104 * 1024); e != hipSuccess) return e;
+        const int per_cu = OccupancyCache::get(integer_round ? 6 : 7, reinterpret_cast<const void *>(kr), threads, lds_r);
+        int blocks = device_cus() * per_cu;
+        blocks = rows < blocks ? rows : blocks;
+        MM_LAUNCH(kr, dim3(blocks), dim3(threads), lds_r, stream, (const uint16_t *)src, (const uint16_t *)weight, eps, rows, K, idx, KN, KS, KO,
+                  oN, oS, oO, sfN, sfS, sfO, slot);
+        return hipGetLastError();
+    }
     const size_t lds = (size_t)K * (products ? 4 : 2) + (size_t)(P > threads ? P : threads) * 4 + (size_t)KS / 4 * 3 + KO;
     // 256 / 512 / 1024 threads: K <= 8192 / 16384 / 32768 (the 1024-thread variant is limited to 128 registers and spills a few)
     auto kern = products ? (integer_round ? rmsnorm_quantize_products_kernel<true> : rmsnorm_quantize_products_kernel<false>)

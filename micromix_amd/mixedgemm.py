@@ -605,6 +605,55 @@ def qlinear_decode(X, reorder_index, BN, BS, BO, SFBN, SFBS, SFBO, KN, KS, KO, *
     return out
 
 
+def rmsnorm_qlinear_decode_supported(M, N, KN, KS, KO):
+    """0 / 1 / 2 as qlinear_decode_supported, for the launch with the RMSNorm inside (K <= 8192)"""
+    return int(_lib.load().mm_rmsnorm_qlinear_decode_supported(int(M), int(N), int(KN), int(KS), int(KO)))
+
+
+def rmsnorm_qlinear_decode(X, norm_weight, eps, reorder_index, BN, BS, BO, SFBN, SFBS, SFBO, KN, KS, KO, *, bias=None, rounding="reference",
+                           integer_round=True, out=None):
+    """rmsnorm_quantize_x + matmul (+ bias) as ONE launch for M <= 8 rows: what a decoder layer of the reference runs in front of
+    q/k/v and gate/up (qLlamaLayer.py: input_layernorm / post_attention_layernorm fused into the quantizer, rmsnorm.cu:95-352, then
+    qLinearLayer.py:58-74).  Bit-identical to `rmsnorm_quantize_x` followed by `matmul`.  X [M, K] bf16, norm_weight [K] bf16."""
+    lib = _lib.load()
+    dev = X.device
+    index = dev.index
+    if not (X.is_cuda and _ok(X, torch.bfloat16, index) and _ok(reorder_index, torch.int16, index) and _ok(norm_weight, torch.bfloat16, index)):
+        _check_tensor(X, "X", torch.bfloat16)
+        _check_tensor(norm_weight, "norm_weight", torch.bfloat16, dev)
+        _check_tensor(reorder_index, "reorder_index", torch.int16, dev)
+    for n, t in (("BN", BN), ("BS", BS), ("BO", BO), ("SFBN", SFBN), ("SFBS", SFBS), ("SFBO", SFBO)):
+        if not _ok(t, torch.uint8, index):
+            _check_tensor(t, n, torch.uint8, dev)
+    KN, KS, KO = int(KN), int(KS), int(KO)
+    M, K = X.shape
+    N = BN.size(0)
+    if K != KN + KS + KO or reorder_index.numel() != K or norm_weight.numel() != K:
+        _lib.check(_lib.MM_ERR_BAD_SPLIT, "rmsnorm_quantize_x")
+    same = BS.size(1) == KS // 4 * 3 and BO.size(1) == KO
+    w4 = BS.size(1) == KS // 2 and BO.size(1) == KO // 2
+    if BN.size(1) != KN // 2 or not (same or w4) or BS.size(0) != N or BO.size(0) != N:
+        raise RuntimeError("packed weights do not match (KN, KS, KO)")
+    wmode = _lib.MM_W_MATCH if same else _lib.MM_W_FP4
+    if (SFBN.numel() < _sf_bytes_w(N, KN) or SFBS.numel() < _sf_bytes_w(N, KS) or SFBO.numel() < _sf_bytes_w(N, KO)):
+        raise RuntimeError("weight scale tensors are too small")
+    if rounding not in ("reference", "fused"):
+        raise ValueError("rounding must be 'reference' or 'fused'")
+    flags = (_lib.MM_ROUND_PER_SEGMENT if rounding == "reference" else _lib.MM_ROUND_ONCE) | (0 if integer_round else _lib.MM_NORM_NO_INTEGER_ROUND)
+    if bias is not None and (not _ok(bias, torch.bfloat16, index) or bias.numel() != N):
+        _check_tensor(bias, "bias", torch.bfloat16, dev)
+        raise RuntimeError("bias must have N elements")
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+    with _on_device(index):
+        st = lib.mm_rmsnorm_qlinear_decode(_ptr(X), _ptr(norm_weight), float(eps), _ptr(reorder_index), _ptr(BN), _ptr(BS), _ptr(BO), _ptr(SFBN),
+                                           _ptr(SFBS), _ptr(SFBO), M, N, KN, KS, KO, wmode, flags, _ptr(bias) if bias is not None else None,
+                                           _ptr(out), _stream_ptr(dev))
+    if st:
+        _lib.check(st, "rmsnorm_qlinear_decode")
+    return out
+
+
 def _direct(src_a, src_b, KN, KS, KO, mode, what):
     """shared body of activate_quantize_x / downproj_quantize_w / downproj_quantize_w4 (bindings.cpp:307-387)."""
     lib = _lib.load()

@@ -80,6 +80,7 @@ def test_every_csrc_header_is_a_build_dependency():
 
 
 STREAM_OK = ("_ZN2mm6stream21mx_gemm_stream_kernelILi2ELi1ELi2ELi8ELb1EEEvNS_8GemmArgsE: ; @x\n"
+             "\tv_accvgpr_write_b32 a[0], 0\n"
              "\tbuffer_load_dwordx2 v[10:11], v17, s[8:11], s1 offen\n"
              "\tbuffer_load_dwordx4 v18, s[12:15], s2 offen lds\n"
              "\tv_add_u32_e32 v3, v4, v5\n"
@@ -111,6 +112,11 @@ def test_the_stream_guard_detects_planted_violations():
     }
     for what, text in planted.items():
         assert c.check_stream(text)[0], what
+    # in FRONT of the kernel's first accumulator instruction (the quantization phase of the kernels that quantize their rows themselves)
+    # the compiler may park values there -- unless a later branch can bring execution back in front of it
+    prefix = STREAM_OK.replace("\tv_accvgpr_write_b32 a[0], 0\n", ".LBB0_1:\n\tv_accvgpr_write_b32 a2, v7\n\tv_accvgpr_read_b32 v20, a2\n\tv_accvgpr_write_b32 a[0], 0\n")
+    assert not c.check_stream(prefix)[0]
+    assert c.check_stream(prefix.replace("\tv_accvgpr_read_b32 v1, a[23]\n", "\tv_accvgpr_read_b32 v1, a[23]\n\ts_cbranch_scc1 .LBB0_1\n"))[0]
     with pytest.raises(RuntimeError, match="asm-owned registers"):
         c.verify_stream(planted["scratch"])
     with pytest.raises(RuntimeError, match="expected >="):
