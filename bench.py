@@ -215,7 +215,7 @@ def llama_layer(dev, lib, mixedgemm, x, steps):
         inside: four launches, norms included"""
         L = layer0 if L is None else L
         m = xm.size(0)
-        if mixedgemm.rmsnorm_qlinear_decode_supported(m, H + 2 * NKV, *in_split):
+        if mixedgemm.rmsnorm_qlinear_decode_supported(m, H + 2 * NKV, *in_split) == 2:
             mixedgemm.rmsnorm_qlinear_decode(xm, normw, 1e-5, idx, *L["qkv"], *in_split)      # norm + quantize + GEMM in one launch
         else:
             mm(mixedgemm.rmsnorm_quantize_x(xm, normw, 1e-5, idx, *in_split), L["qkv"])
@@ -234,7 +234,7 @@ def llama_layer(dev, lib, mixedgemm, x, steps):
     def launches(m):
         if m > 64:
             return 7
-        n = 1 if mixedgemm.rmsnorm_qlinear_decode_supported(m, H + 2 * NKV, *in_split) else 2
+        n = 1 if mixedgemm.rmsnorm_qlinear_decode_supported(m, H + 2 * NKV, *in_split) == 2 else 2
         n += 1 if mixedgemm.qlinear_decode_supported(m, H, *in_split) else 2
         if mixedgemm.rmsnorm_qlinear_decode_supported(m, 2 * I, *in_split) == 2 and mixedgemm.down_activate_decode_supported(m, H, *down_split) == 2:
             return n + 2

@@ -63,9 +63,9 @@ def check_counted(asm_text):
 # the model, so the scan is exact for straight-line code and silent across branches).
 # ---------------------------------------------------------------------------------------------------------
 STREAM_OWN = re.compile(r"^\s*(v_mfma_scale_f32_16x16x128_f8f6f4|v_accvgpr_read_b32|v_accvgpr_write_b32)\b")
-STREAM_KERNEL = re.compile(r"^(_ZN2mm6stream\d+(mx_gemm_stream_kernel|mx_gemm_stream_grouped_kernel|mx_qlinear_stream_kernel)I((?:Li\d+E)+)Lb[01]E\w*):[^\n]*\n(.*?)\.end_amdhsa_kernel",
+STREAM_KERNEL = re.compile(r"^(_ZN2mm6stream\d+(mx_gemm_stream_kernel|mx_gemm_stream_grouped_kernel|mx_qlinear_stream_kernel|mx_qlinear_stream_rms_kernel)I((?:Li\d+E)+)Lb[01]E\w*):[^\n]*\n(.*?)\.end_amdhsa_kernel",
                            re.S | re.M)
-EXPECTED_STREAM_KERNELS = 52   # 20 plain + 16 grouped + 16 with the quantizer inside
+EXPECTED_STREAM_KERNELS = 60   # 20 plain + 16 grouped + 16 with the quantizer inside + 8 with norm and quantizer inside
 VMEM = re.compile(r"^\s*(buffer_|global_|scratch_|flat_)(load|store|atomic)")
 
 
@@ -82,7 +82,7 @@ def stream_nacc(kind, ints):
     """accumulator registers of an instantiation, from the template arguments in its mangled name: <F, T16, D, NW> (plain, grouped) or
     <F, D, NW> with T16 = 1 (quantizer inside)"""
     v = [int(x) for x in re.findall(r"Li(\d+)E", ints)]
-    f, t16 = (v[0], 1) if kind == "mx_qlinear_stream_kernel" else (v[0], v[1])
+    f, t16 = (v[0], 1) if kind.startswith("mx_qlinear_stream") else (v[0], v[1])
     return 12 * f * t16
 
 
@@ -133,8 +133,7 @@ def check_stream(asm_text):
         first = next((k for k, c in enumerate(lines) if STREAM_OWN.match(c) and re.search(r"\ba\[", c)), len(lines))
         early_labels = {m2.group(1) for c in lines[:first] for m2 in [re.match(r"^(\.?\w+):\s*$", c.strip())] if m2}
         reentered = [c.strip() for c in lines[first:] if re.match(r"\s*s_c?branch\w*\s", c) and c.split()[-1] in early_labels]
-        for c in reentered:
-            bad.append((sym, "branches back in front of the first accumulator instruction: " + c))
+        parked = []          # compiler uses of accumulator AGPRs in front of that point: fine unless that code can run again
         for k, code in enumerate(lines):
             if not code.strip():
                 continue
@@ -149,8 +148,11 @@ def check_stream(asm_text):
             if STREAM_OWN.match(code) is not None and not re.search(r"\ba\d+\b", code):
                 continue
             if k < first:
-                continue            # the accumulators are not live yet (see above)
+                parked.append(code.strip())     # the accumulators are not live yet (see above)
+                continue
             bad.append((sym, code.strip()))
+        if parked and reentered:
+            bad.append((sym, f"parks values in accumulator AGPRs in front of the first accumulator instruction ({parked[0]}) and can branch back there: {reentered[0]}"))
         bad += [(sym, "reads a load destination before its s_waitcnt vmcnt: " + c) for c in pending_load_violations(body)]
     return bad, examined
 

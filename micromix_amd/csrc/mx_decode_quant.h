@@ -6,6 +6,12 @@
 #include "mx_direct_convert.h"
 #include "mx_rms_convert.h"
 
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MM_DQ_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+#else
+#define MM_DQ_SCHED_BARRIER() do { } while (0)
+#endif
+
 namespace mm {
 namespace dq {
 
@@ -67,6 +73,9 @@ __device__ __forceinline__ uint32_t rms_quantize_group(const uint8_t *__restrict
         us2 m;
         __builtin_memcpy(&m, &mag, 4);
         amax2 = __builtin_elementwise_max(amax2, m);
+        // (the scheduler would otherwise hoist all 64 two-byte LDS reads in front of the arithmetic: 64 live values, and the kernel's
+        // register count decides how many workgroups a CU holds)
+        if ((i & 1) == 1) { MM_DQ_SCHED_BARRIER(); }
     }
     const uint32_t amax = amax2[0] > amax2[1] ? amax2[0] : amax2[1];
     int e;
@@ -81,7 +90,10 @@ __device__ __forceinline__ uint32_t rms_quantize_group(const uint8_t *__restrict
 // with loads of its own that the compiler does not track (mx_gemm_stream.hip's DMA ring) issues them there, so that they fly during
 // the arithmetic and the compiler's own wait counts never have to cover them.
 struct NoHook { __device__ __forceinline__ void operator()() const {} };
-template <int NT, class Hook = NoHook>
+// RMS: the norm runs in front of the quantization (a.norm_w etc.).  A template parameter, not a run-time test: with both paths in one
+// kernel the register allocation is the larger path's, and the streaming kernels' quantizing variants lost a resident workgroup per CU
+// to it (87 -> 121 VGPRs; gate/up at M = 1 9.3 -> 13.4 us, round 5).
+template <int NT, bool RMS = false, class Hook = NoHook>
 __device__ __forceinline__ LdsMap quantize_rows_to_lds(const QuantIn &a, uint8_t *smem, Hook staged = Hook()) {
     const int Kt = a.K[0] + a.K[1] + a.K[2], Gt = Kt >> 5;
     const int gN = a.K[0] >> 5, gS = a.K[1] >> 5;
@@ -90,7 +102,7 @@ __device__ __forceinline__ LdsMap quantize_rows_to_lds(const QuantIn &a, uint8_t
     uint8_t *opN = stage + (size_t)a.stage_rows * Kt * 2, *opS = opN + a.M * pN, *opO = opS + a.M * pS;
     uint8_t *scales = opO + a.M * pO;
     // with the norm: [norm weights | partial sums | rvar] behind the 16-byte rounded operands (rms_bytes)
-    const bool rms = a.norm_w != nullptr;
+    constexpr bool rms = RMS;
     const int P = rms_pow2(Gt);
     uint8_t *wvec = opN + ((operand_bytes(a.M, a.K) + 15) & ~(size_t)15);
     float *part = reinterpret_cast<float *>(wvec + (size_t)Kt * 2), *rvar = part + (size_t)a.M * P;
@@ -117,11 +129,11 @@ __device__ __forceinline__ LdsMap quantize_rows_to_lds(const QuantIn &a, uint8_t
         if (t0 < nr * Gt) load_ix(t0 % Gt, ix);
         const uint4 *grow = reinterpret_cast<const uint4 *>(a.X + (size_t)r0 * Kt);
         for (int c = threadIdx.x; c < nr * (Kt >> 3); c += NT) reinterpret_cast<uint4 *>(stage)[c] = grow[c];
-        if (rms && r0 == 0)
+        if constexpr (rms) if (r0 == 0)
             for (int c = threadIdx.x; c < (Kt >> 3); c += NT) reinterpret_cast<uint4 *>(wvec)[c] = reinterpret_cast<const uint4 *>(a.norm_w)[c];
         __syncthreads();
         if (r0 == 0) staged();
-        if (rms) {
+        if constexpr (rms) {
             // the reference's sum of squares per row: Gt group threads' partial sums (zero padded to P), then the halving tree, one wave per row
             for (int u = threadIdx.x; u < nr * P; u += NT) {
                 const int rr = u / P, t = u - rr * P;
@@ -140,7 +152,7 @@ __device__ __forceinline__ LdsMap quantize_rows_to_lds(const QuantIn &a, uint8_t
             const uint8_t *row = stage + (size_t)rr * Kt * 2;
             if (t != t0) load_ix(g, ix);
             uint32_t byte;
-            if (rms) {
+            if constexpr (rms) {
                 const float rv = rvar[r];
                 if (g < gN) byte = rms_quantize_group<EL_FP4>(row, wvec, ix, rv, a.int_round != 0, opN + r * pN + g * 16);
                 else if (g < gN + gS) byte = rms_quantize_group<EL_FP6>(row, wvec, ix, rv, a.int_round != 0, opS + r * pS + (g - gN) * 24);
@@ -177,7 +189,7 @@ __device__ __forceinline__ dq_v4u gload16(const void *p) {
     MM_DQ_DEVICE_ONLY(asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(d) : "v"(p) : "memory");)
     return d;
 }
-template <int NT, int AFTER_LOADS, class Request>
+template <int NT, int AFTER_LOADS, bool RMS, class Request>
 __device__ __forceinline__ LdsMap quantize_rows_early(const QuantIn &a, uint8_t *smem, Request request) {
     const int Kt = a.K[0] + a.K[1] + a.K[2], Gt = Kt >> 5;
     const int gN = a.K[0] >> 5, gS = a.K[1] >> 5;
@@ -189,7 +201,13 @@ __device__ __forceinline__ LdsMap quantize_rows_early(const QuantIn &a, uint8_t 
     const int rr = t < groups ? t / Gt : 0, g = t < groups ? t - rr * Gt : 0;
     const uint4 *ip = reinterpret_cast<const uint4 *>(a.idx + (size_t)g * 32);
     const uint4 *grow = reinterpret_cast<const uint4 *>(a.X);
-    dq_v4u iq[4], rq[EARLY_RL];
+    // with the norm: [norm weights | partial sums | rvar] behind the 16-byte rounded operands (rms_bytes); one more load per thread
+    // (the launcher admits the early path with the norm only when the weight vector is at most one chunk per thread: K / 8 <= NT)
+    constexpr bool rms = RMS;
+    const int P = rms_pow2(Gt);
+    uint8_t *wvec = opN + ((operand_bytes(a.M, a.K) + 15) & ~(size_t)15);
+    float *part = reinterpret_cast<float *>(wvec + (size_t)Kt * 2), *rvar = part + (size_t)a.M * P;
+    dq_v4u iq[4], rq[EARLY_RL], wq = {0u, 0u, 0u, 0u};
 #pragma unroll
     for (int i = 0; i < 4; ++i) iq[i] = gload16(ip + i);
 #pragma unroll
@@ -197,6 +215,7 @@ __device__ __forceinline__ LdsMap quantize_rows_early(const QuantIn &a, uint8_t 
         const int c = t + k * NT;
         rq[k] = gload16(grow + (c < chunks ? c : chunks - 1));       // (past the end: the last chunk again, not stored)
     }
+    if constexpr (rms) wq = gload16(reinterpret_cast<const uint4 *>(a.norm_w) + (t < (Kt >> 3) ? t : 0));     // (wave-uniform branch; see the wait below)
     const bool requested = request();
     if (requested) { MM_DQ_DEVICE_ONLY(asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AFTER_LOADS) : "memory");) }
     else { MM_DQ_DEVICE_ONLY(asm volatile("s_waitcnt vmcnt(0)" ::: "memory");) }
@@ -204,12 +223,27 @@ __device__ __forceinline__ LdsMap quantize_rows_early(const QuantIn &a, uint8_t 
     for (int i = 0; i < 4; ++i) { MM_DQ_DEVICE_ONLY(asm volatile("" : "+v"(iq[i]));) }
 #pragma unroll
     for (int k = 0; k < EARLY_RL; ++k) { MM_DQ_DEVICE_ONLY(asm volatile("" : "+v"(rq[k]));) }
+    if constexpr (rms) { MM_DQ_DEVICE_ONLY(asm volatile("" : "+v"(wq));) }
 #pragma unroll
     for (int k = 0; k < EARLY_RL; ++k) {
         const int c = t + k * NT;
         if (c < chunks) reinterpret_cast<dq_v4u *>(stage)[c] = rq[k];
     }
+    if constexpr (rms) if (t < (Kt >> 3)) reinterpret_cast<dq_v4u *>(wvec)[t] = wq;
     __syncthreads();
+    if constexpr (rms) {      // as quantize_rows_to_lds: partial sums in the reference's order, the halving tree by one wave per row
+        for (int u = t; u < a.M * P; u += NT) {
+            const int r2 = u / P, t2 = u - r2 * P;
+            const uint4 *row4 = reinterpret_cast<const uint4 *>(stage + (size_t)r2 * Kt * 2);
+            part[u] = t2 < Gt ? rms_thread_sum(t2, Gt, [&](int q) { return row4[q]; }) : 0.0f;
+        }
+        __syncthreads();
+        for (int r2 = t >> 6; r2 < a.M; r2 += NT / 64) {
+            const float rv = rms_tree_rvar(part + r2 * P, P, t & 63, Kt, a.eps);
+            if ((t & 63) == 0) rvar[r2] = rv;
+        }
+        __syncthreads();
+    }
     if (t < groups) {
         uint32_t ix[16];
 #pragma unroll
@@ -221,9 +255,16 @@ __device__ __forceinline__ LdsMap quantize_rows_early(const QuantIn &a, uint8_t 
         }
         const uint8_t *row = stage + (size_t)rr * Kt * 2;
         uint32_t byte;
-        if (g < gN) byte = quantize_group<EL_FP4>(row, ix, opN + rr * pN + g * 16);
-        else if (g < gN + gS) byte = quantize_group<EL_FP6>(row, ix, opS + rr * pS + (g - gN) * 24);
-        else byte = quantize_group<EL_FP8>(row, ix, opO + rr * pO + (g - gN - gS) * 32);
+        if constexpr (rms) {
+            const float rv = rvar[rr];
+            if (g < gN) byte = rms_quantize_group<EL_FP4>(row, wvec, ix, rv, a.int_round != 0, opN + rr * pN + g * 16);
+            else if (g < gN + gS) byte = rms_quantize_group<EL_FP6>(row, wvec, ix, rv, a.int_round != 0, opS + rr * pS + (g - gN) * 24);
+            else byte = rms_quantize_group<EL_FP8>(row, wvec, ix, rv, a.int_round != 0, opO + rr * pO + (g - gN - gS) * 32);
+        } else {
+            if (g < gN) byte = quantize_group<EL_FP4>(row, ix, opN + rr * pN + g * 16);
+            else if (g < gN + gS) byte = quantize_group<EL_FP6>(row, ix, opS + rr * pS + (g - gN) * 24);
+            else byte = quantize_group<EL_FP8>(row, ix, opO + rr * pO + (g - gN - gS) * 32);
+        }
         scales[rr * Gt + g] = (uint8_t)byte;
     }
     __syncthreads();

@@ -64,6 +64,9 @@ typedef int rsrc_t __attribute__((ext_vector_type(4)));
 #ifndef MM_STREAM_DBG
 #define MM_STREAM_DBG 0
 #endif
+#ifndef MM_STREAM_ACCZERO_EARLY
+#define MM_STREAM_ACCZERO_EARLY 0
+#endif
 
 
 // 128-bit raw buffer descriptor {base_lo, base_hi(16 bits) | stride 0, num_records (bytes), flags}, every word provably
@@ -187,7 +190,7 @@ __device__ unsigned long long *g_stream_clock;
 // its first batch of rows is staged it requests its first D slabs of weights, and the activation fragments and scales of a slab come
 // from that LDS copy (rows in the reference's packed layout, as in qlinear_decode.hip).  `qbytes` = the quantization's LDS range in
 // front of the rings.
-template <int F, int T16, int D, int NW, bool W4, bool QUANT = false>
+template <int F, int T16, int D, int NW, bool W4, bool QUANT = false, bool RMS = false>
 __device__ __forceinline__ void stream_body(const GemmArgs &a, const dq::QuantIn &qi = dq::QuantIn(), int qbytes = 0) {
     static_assert(T16 <= 4, "64 token rows: row groups 0 and 1 of the activation scale atoms, both in the 8 bytes a lane loads");
     static_assert(!QUANT || T16 == 1, "M <= 8");
@@ -257,6 +260,9 @@ __device__ __forceinline__ void stream_body(const GemmArgs &a, const dq::QuantIn
     const int rd8a = (li >> 3) * 1024 + (8 * (li & 7) + (h ^ s8)) * 16, rd8b = (li >> 3) * 1024 + (8 * (li & 7) + ((4 + h) ^ s8)) * 16;
 
     static_assert(12 * ACC <= 192, "a[0:191]");
+#if MM_STREAM_ACCZERO_EARLY       // A/B builds only (round 4's placement: in front of the quantization phase -- not safe with the norm inside, see below)
+    static_for<12 * ACC>([&](auto r_) { acc_zero<decltype(r_)::value, 12 * ACC>(); });
+#endif
 
     // slab s of segment G into slot d: RG::LOADS vector-memory instructions, whatever the segment
     auto issue_g = [&](Slot &q, int d, auto G_, int s) {
@@ -368,8 +374,8 @@ __device__ __forceinline__ void stream_body(const GemmArgs &a, const dq::QuantIn
     };
     if constexpr (QUANT) {
         if (qi.mode == 1) L = dq::activate_rows_to_lds<NT>(qi, smem_all, [&]() { prime(); });
-        else if (qi.early) L = dq::quantize_rows_early<NT, D * RG::LOADS>(qi, smem_all, prime);
-        else L = dq::quantize_rows_to_lds<NT>(qi, smem_all, [&]() { prime(); });
+        else if (qi.early) L = dq::quantize_rows_early<NT, D * RG::LOADS, RMS>(qi, smem_all, prime);
+        else L = dq::quantize_rows_to_lds<NT, RMS>(qi, smem_all, [&]() { prime(); });
         const int rr = li < a.M ? li : 0;
         qx[0] = L.opN + rr * L.pN + 16 * h;
         qx[1] = L.opS + rr * L.pS + 24 * h;
@@ -382,7 +388,9 @@ __device__ __forceinline__ void stream_body(const GemmArgs &a, const dq::QuantIn
     }
     // the accumulators are cleared HERE, behind the quantization phase: nothing asm-owned is live while the compiler allocates that
     // phase's registers (with the norm inside it once parked values in a[2:3]; the build guard caught it)
+#if !MM_STREAM_ACCZERO_EARLY
     static_for<12 * ACC>([&](auto r_) { acc_zero<decltype(r_)::value, 12 * ACC>(); });
+#endif
     if (cnt > 0) {
         MM_STAMP(1);
         for (int r = 0; r + 1 < rounds; ++r) {
@@ -549,9 +557,22 @@ template <int F, int D, int NW, bool W4>
 __global__ void __launch_bounds__(64 * NW) mx_qlinear_stream_kernel(GemmArgs a, dq::QuantIn qi, int qbytes) {
     stream_body<F, 1, D, NW, W4, true>(a, qi, qbytes);
 }
-
+// ... with the RMSNorm in front of the quantization (mm_rmsnorm_qlinear_decode): kernels of their own, see dq::quantize_rows_to_lds
+// (105 VGPRs + 24 accumulators at F = 2: ONE 8-wave workgroup per CU where the kernel without the norm holds two.  Bounding it with
+// __launch_bounds__(512, 4) made hipcc split the file 64 + 64, park values in a[0:23] and copy pending load destinations before their
+// wait -- the build guard refused all of it.  The Llama layer's wide launch, gate | up at N = 28672, runs F = 4 on 4 waves: three
+// workgroups per CU with and without the norm.)
 template <int F, int D, int NW, bool W4>
+__global__ void __launch_bounds__(64 * NW) mx_qlinear_stream_rms_kernel(GemmArgs a, dq::QuantIn qi, int qbytes) {
+    stream_body<F, 1, D, NW, W4, true, true>(a, qi, qbytes);
+}
+
+template <int F, int D, int NW, bool W4, bool RMS = false>
 static hipError_t launch_quant(const GemmArgs &a, dq::QuantIn qi, hipStream_t stream) {
+    if constexpr (!RMS && ((F == 4 && D == 2 && NW == 4) || (F == 2 && D == 2 && NW == 8) || (F == 1 && NW == 8 && (D == 3 || D == 4)))) {
+        if (qi.norm_w != nullptr) return launch_quant<F, D, NW, W4, true>(a, qi, stream);      // (the configurations the default dispatch uses)
+    }
+    if (!RMS && qi.norm_w != nullptr) return hipErrorInvalidValue;       // (a kernel-developer override picked a configuration without a norm variant)
     const int present = (a.K[0] ? 1 : 0) + (a.K[1] ? 1 : 0) + (a.K[2] ? 1 : 0);
     const size_t red_bytes = (size_t)NW * present * F * 4 * 64 * sizeof(float), ring_bytes = (size_t)NW * D * Ring<F, 1, W4, true>::SLOT;
     const size_t tail = red_bytes > ring_bytes ? red_bytes : ring_bytes;
@@ -570,16 +591,18 @@ static hipError_t launch_quant(const GemmArgs &a, dq::QuantIn qi, hipStream_t st
     qi.stage_rows = (int)rows;
     qi.early = (qi.mode != 1 && rows >= (size_t)a.M && (size_t)a.M * (Kt / 32) <= 64u * NW && (size_t)a.M * (Kt / 8) <= 64u * NW * dq::EARLY_RL) ? 1 : 0;
     static const int early_on = getenv("MICROMIX_DECODE_EARLY") ? atoi(getenv("MICROMIX_DECODE_EARLY")) : 1;   // kernel-developer override
-    if (!early_on || qi.norm_w != nullptr) qi.early = 0;      // (the norm runs in the generic phase: its partial sums need the staged rows first)
+    if (!early_on) qi.early = 0;
+    if (qi.norm_w != nullptr && Kt / 8 > 64u * NW) qi.early = 0;     // with the norm the early phase loads the weight vector as one chunk per thread
     const size_t qbytes = rows * Kt * 2 + ops, lds = qbytes + tail;
     if (lds > LDS_WG) return hipErrorInvalidValue;      // (every mode: the supported() predicates keep callers away from this)
     static DynamicLdsOnce once;
+    auto kern = [] { if constexpr (RMS) return mx_qlinear_stream_rms_kernel<F, D, NW, W4>; else return mx_qlinear_stream_kernel<F, D, NW, W4>; }();
     if (lds > 65536) {
-        hipError_t e = once.ensure(reinterpret_cast<const void *>(mx_qlinear_stream_kernel<F, D, NW, W4>), (int)LDS_WG);
+        hipError_t e = once.ensure(reinterpret_cast<const void *>(kern), (int)LDS_WG);
         if (e != hipSuccess) return e;
     }
     const int blocks = (a.N + 16 * F - 1) / (16 * F);
-    MM_LAUNCH((mx_qlinear_stream_kernel<F, D, NW, W4>), dim3(blocks), dim3(64 * NW), lds, stream, a, qi, (int)qbytes);
+    MM_LAUNCH(kern, dim3(blocks), dim3(64 * NW), lds, stream, a, qi, (int)qbytes);
     return hipGetLastError();
 }
 

@@ -148,20 +148,21 @@ __device__ __forceinline__ void run_segment(v16f &acc, const uint8_t *xl, int xp
 }
 
 using dq::LdsMap;
+template <bool RMS>
 __device__ __forceinline__ LdsMap quantize_rows_to_lds(const Args &a, uint8_t *smem) {
     dq::QuantIn q;
     q.X = a.X; q.idx = a.idx; q.M = a.M; q.stage_rows = a.stage_rows;
     q.K[0] = a.K[0]; q.K[1] = a.K[1]; q.K[2] = a.K[2];
     q.mode = 0; q.early = 0;
     q.norm_w = a.norm_w; q.eps = a.eps; q.int_round = a.int_round;
-    return dq::quantize_rows_to_lds<NT>(q, smem);
+    return dq::quantize_rows_to_lds<NT, RMS>(q, smem);
 }
 
-template <bool W4>
+template <bool W4, bool RMS = false>
 __global__ void __launch_bounds__(NT) qlinear_decode_kernel(Args a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];   // [row stage | opN | opS | opO | scales]
     __shared__ float red[NW][16][64];
-    const LdsMap L = quantize_rows_to_lds(a, smem);
+    const LdsMap L = quantize_rows_to_lds<RMS>(a, smem);
     const uint8_t *opN = L.opN, *opS = L.opS, *opO = L.opO, *scales = L.scales;
     const int pN = L.pN, pS = L.pS, pO = L.pO, Gt = L.Gt, gN = L.gN, gS = L.gS;
 
@@ -308,11 +309,11 @@ __device__ __forceinline__ void run_segment16(v4f &acc, const uint8_t *xl, int x
     }
 }
 
-template <bool W4>
+template <bool W4, bool RMS = false>
 __global__ void __launch_bounds__(NT) qlinear_decode16_kernel(Args a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     __shared__ float red[NW][4][64];
-    const LdsMap L = quantize_rows_to_lds(a, smem);
+    const LdsMap L = quantize_rows_to_lds<RMS>(a, smem);
     const int n0 = blockIdx.x * BN16;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nseg[3] = {a.K[0] >> 7, a.K[1] >> 7, a.K[2] >> 7};
@@ -372,10 +373,18 @@ int qlinear_decode_supported(int M, int N, const int K[3], bool rms) {
     // layers wide enough for the streaming kernel's workgroup-local quantization (mx_gemm_stream.hip): it beats quantize + GEMM at
     // M = 1 and 2 (gate/up 10.6-12.7 -> 8.5-9.3 us, fused gate + up 18.3-19.0 -> 16.2-17.7) and ties or loses from M = 4 on
     // (every workgroup repeats the quantization: beyond ~4 rounds of workgroups -- not measured, N > 32768 -- one separate quantize launch is cheaper)
-    if (qlinear_stream_supported(M, N, K, rms)) return (M <= 2 && N <= 32768) ? 2 : 1;
+    // With the norm inside (round 5, tools/time_decode.py, K = 4096, us, rmsnorm_quantize + GEMM / one launch): every workgroup repeats
+    // the sum of squares too.  Streaming kernel: gate | up N = 28672 (F = 4 on 4 waves) M = 1 18.3 / 17.4, M = 4 18.3 / 28.2; N = 14336
+    // (F = 2 on 8 waves: 105 + 24 registers, ONE workgroup per CU) M = 1 11.4 / 16.0.  First fused kernel: q | k | v M = 1 11.5 / 9.1,
+    // M = 4 11.6 / 11.8; q/o M = 1 9.3 / 7.9, M = 4 9.7 / 10.5.
+    if (qlinear_stream_supported(M, N, K, rms)) {
+        if (rms) return (M == 1 && (N + 31) / 32 > 2 * device_cus() && N <= 32768) ? 2 : 1;
+        return (M <= 2 && N <= 32768) ? 2 : 1;
+    }
     const int feat = decode_features(N), cus = device_cus();
     const int rounds = ((N + feat - 1) / feat + cus - 1) / cus;
     const int passes = (int)((M * (Kt / 32) + decode::NT - 1) / decode::NT);
+    if (rms) return (rounds == 1 && M <= 2) ? 2 : 1;
     return rounds * passes <= 2 ? 2 : 1;
 }
 
@@ -408,10 +417,12 @@ hipError_t launch_qlinear_decode(const void *X, const int16_t *idx, const uint8_
     a.stage_rows = stage_rows;
     const size_t lds = (size_t)stage_rows * Kt * 2 + ops;
     const bool f16 = decode_features(N) == 16;
-    auto kern = f16 ? (w4 ? qlinear_decode16_kernel<true> : qlinear_decode16_kernel<false>)
-                    : (w4 ? qlinear_decode_kernel<true> : qlinear_decode_kernel<false>);
-    static DynamicLdsOnce done[4];
-    if (hipError_t e = done[(f16 ? 2 : 0) + (w4 ? 0 : 1)].ensure(reinterpret_cast<const void *>(kern), (int)DECODE_LDS_MAX); e != hipSuccess)
+    auto kern = rms ? (f16 ? (w4 ? qlinear_decode16_kernel<true, true> : qlinear_decode16_kernel<false, true>)
+                           : (w4 ? qlinear_decode_kernel<true, true> : qlinear_decode_kernel<false, true>))
+                    : (f16 ? (w4 ? qlinear_decode16_kernel<true> : qlinear_decode16_kernel<false>)
+                           : (w4 ? qlinear_decode_kernel<true> : qlinear_decode_kernel<false>));
+    static DynamicLdsOnce done[8];
+    if (hipError_t e = done[(rms ? 4 : 0) + (f16 ? 2 : 0) + (w4 ? 0 : 1)].ensure(reinterpret_cast<const void *>(kern), (int)DECODE_LDS_MAX); e != hipSuccess)
         return e;
     const int feat = f16 ? BN16 : BN;
     int blocks = (N + feat - 1) / feat;

@@ -136,6 +136,26 @@ def _forward(layer, x):
     return y, bsz, q_len
 
 
+def _forward_norm(layer, x, norm_weight, eps):
+    """RMSNorm(x; norm_weight, eps) -> layer: the reference's caller pattern `layer(rmsnorm_quantize_x(x, w, eps, idx, p4, p6, p8))`
+    (model/qLlamaLayer.py: input_layernorm -> q/k/v, post_attention_layernorm -> gate/up; bindings.cpp:257-303).  At decode sizes where
+    it is faster the norm, the quantization and the GEMM are ONE launch (`mixedgemm.rmsnorm_qlinear_decode`); the bytes are the same."""
+    bsz, q_len, k = x.shape
+    m = bsz * q_len
+    x2d = x.reshape(m, k).contiguous()
+    split = (layer.p4_num, layer.p6_num, layer.p8_num)
+    bias = layer.bias
+    if bias is not None and bias.device != x.device:
+        bias = bias.to(x.device)
+    rounding = getattr(layer, "rounding", "reference")
+    if _DECODE_FUSED and 0 < m <= 8 and mixedgemm.rmsnorm_qlinear_decode_supported(m, layer.out_features, *split) == 2:
+        return mixedgemm.rmsnorm_qlinear_decode(x2d, norm_weight, eps, layer.reorder_index, layer.BN, layer.BS, layer.BO, layer.SFBN, layer.SFBS,
+                                                layer.SFBO, *split, bias=bias, rounding=rounding), bsz, q_len
+    q = mixedgemm.rmsnorm_quantize_x(x2d, norm_weight, eps, layer.reorder_index, *split)
+    return mixedgemm.matmul(q[0], layer.BN, q[1], layer.BS, q[2], layer.BO, q[3], layer.SFBN, q[4], layer.SFBS, q[5], layer.SFBO,
+                            bias=bias, rounding=rounding), bsz, q_len
+
+
 def find_qlinear_layers(module, name=""):
     """qLinearLayer.py:8-17."""
     if type(module) == QLinearLayer:
@@ -190,6 +210,12 @@ class QLinearLayer(nn.Module):
         # the Mixtral expert caller passes bsz = None with 2-D token batches (qMixtralLayer.py:507-519)
         return y.reshape(bsz, q_len, -1) if bsz is not None else y.reshape(q_len, -1)
 
+    @torch.no_grad()
+    def forward_norm(self, x, norm_weight, eps):
+        """layer(RMSNorm(x)): x [bsz, q_len, K] bf16 -> [bsz, q_len, N]; see _forward_norm"""
+        y, bsz, q_len = _forward_norm(self, x, norm_weight, eps)
+        return y.reshape(bsz, q_len, -1)
+
 
 class FusedQLinear(nn.Module):
     """Several QLinearLayers that read the SAME input (q/k/v, gate/up) as ONE GEMM.
@@ -237,6 +263,12 @@ class FusedQLinear(nn.Module):
             return tuple(t.reshape(q_len, -1) for t in y.split(self.splits, dim=1))
         return tuple(t.reshape(bsz, q_len, -1) for t in y.split(self.splits, dim=1))
 
+    @torch.no_grad()
+    def forward_norm(self, x, norm_weight, eps):
+        """the fused layers on RMSNorm(x) (input_layernorm -> q | k | v as one launch at decode sizes); see _forward_norm"""
+        y, bsz, q_len = _forward_norm(self, x, norm_weight, eps)
+        return tuple(t.reshape(bsz, q_len, -1) for t in y.split(self.splits, dim=1))
+
 
 class FusedMLP(nn.Module):
     """gate_proj, up_proj, act_fn(gate) * up and down_proj of one decoder MLP (model/qLlamaLayer.py:336-387) in three launches
@@ -270,12 +302,24 @@ class FusedMLP(nn.Module):
             self.register_buffer("D_" + name, t)
 
     @torch.no_grad()
-    def forward(self, x):
+    def forward(self, x, norm_weight=None, eps=1e-5):
+        """`norm_weight` given: the MLP of RMSNorm(x) (post_attention_layernorm fused into the quantizer, as the reference's
+        rmsnorm_quantize_x caller does); at M = 1 the norm, the quantization and the gate | up GEMM are one launch"""
         lead = x.shape[:-1]
         x2 = x.reshape(-1, self.hidden).contiguous()
         gu = (self.GU_BN, self.GU_BS, self.GU_BO, self.GU_SFBN, self.GU_SFBS, self.GU_SFBO)
         m = x2.size(0)
         down = (self.D_BN, self.D_BS, self.D_BO, self.D_SFBN, self.D_SFBS, self.D_SFBO)
+        if norm_weight is not None:
+            if m <= 4 and mixedgemm.rmsnorm_qlinear_decode_supported(m, 2 * self.inter, *self.in_split) == 2 \
+                    and mixedgemm.down_activate_decode_supported(m, self.hidden, *self.down_split) == 2:
+                gub = mixedgemm.rmsnorm_qlinear_decode(x2, norm_weight, eps, self.reorder_index, *gu, *self.in_split, rounding=self.rounding)
+                return mixedgemm.down_activate_decode(gub, down, *self.down_split, rounding=self.rounding).reshape(*lead, self.hidden)
+            qx = mixedgemm.rmsnorm_quantize_x(x2, norm_weight, eps, self.reorder_index, *self.in_split)
+            qh = mixedgemm.gate_up_activate(qx, gu, *self.down_split, rounding=self.rounding)
+            y = mixedgemm.matmul(qh[0], self.D_BN, qh[1], self.D_BS, qh[2], self.D_BO, qh[3], self.D_SFBN, qh[4], self.D_SFBS, qh[5],
+                                 self.D_SFBO, rounding=self.rounding)
+            return y.reshape(*lead, self.hidden)
         if m <= 4 and mixedgemm.qlinear_decode_supported(m, 2 * self.inter, *self.in_split) == 2 \
                 and mixedgemm.down_activate_decode_supported(m, self.hidden, *self.down_split) == 2:
             # decode, TWO launches: reorder + quantize + the gate | up GEMM, then down_proj with silu * up + its quantization inside

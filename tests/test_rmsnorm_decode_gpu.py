@@ -85,3 +85,28 @@ def test_supported_range_and_errors(dev):
     assert y.shape == (1, 128) and not y.any()
     with pytest.raises(RuntimeError):
         mixedgemm.rmsnorm_qlinear_decode(x, nw[: k - 8], 1e-5, idx, *b, *split)
+
+
+def test_layers_forward_norm(dev):
+    """QLinearLayer / FusedQLinear.forward_norm and FusedMLP.forward(x, norm_weight): RMSNorm -> layer, byte-identical to the reference's
+    caller pattern (rmsnorm_quantize_x -> forward(tuple)) at decode and prefill sizes"""
+    import torch
+    from micromix_amd.qlinear import FusedMLP, FusedQLinear, QLinearLayer
+    g = torch.Generator().manual_seed(5)
+    k, inter, p8, p6 = 1024, 2048, 384, 128
+    idx = torch.randperm(k, generator=g)
+    lin = lambda n, kk=k, b=False: torch.nn.Linear(kk, n, bias=b, dtype=torch.bfloat16).to(dev)
+    q, kv = QLinearLayer(lin(512, b=True), p8, p6, idx), QLinearLayer(lin(256), p8, p6, idx)
+    fused = FusedQLinear([q, kv])
+    gate, up = QLinearLayer(lin(inter), p8, p6, idx), QLinearLayer(lin(inter), p8, p6, idx)
+    mlp = FusedMLP(gate, up, (torch.randn((k, inter), generator=g) * 0.02).to(torch.bfloat16), (1536, 256, 256))
+    nw = (1.0 + 0.2 * torch.randn((k,), generator=g)).to(torch.bfloat16).to(dev)
+    for m in (1, 2, 8, 70):
+        x = torch.randn((1, m, k), generator=g).to(torch.bfloat16).to(dev)
+        tup = (*mixedgemm.rmsnorm_quantize_x(x.reshape(m, k), nw, 1e-5, q.reorder_index, q.p4_num, q.p6_num, q.p8_num), 1, m)
+        assert torch.equal(q.forward_norm(x, nw, 1e-5), q(tup))
+        yq, ykv = fused.forward_norm(x, nw, 1e-5)
+        assert torch.equal(yq, q(tup)) and torch.equal(ykv, kv(tup))
+        qh = mixedgemm.activate_quantize_x(gate(tup).reshape(m, inter), up(tup).reshape(m, inter), *mlp.down_split)
+        want = mixedgemm.matmul(qh[0], mlp.D_BN, qh[1], mlp.D_BS, qh[2], mlp.D_BO, qh[3], mlp.D_SFBN, qh[4], mlp.D_SFBS, qh[5], mlp.D_SFBO)
+        assert torch.equal(mlp(x, nw, 1e-5).reshape(m, k), want)

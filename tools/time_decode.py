@@ -32,4 +32,13 @@ for name, N, K, split in (("q/o", 4096, 4096, (2048, 128, 1920)), ("qkv fused", 
             lib.mm_matmul(*ptrs, M, N, *split, 1, 0, None, out.data_ptr(), st)
         one = lambda: lib.mm_qlinear_decode(x.data_ptr(), idx.data_ptr(), *[pp(t) for t in b], M, N, *split, 1, 0, None, out.data_ptr(), st)
         assert one() == 0
-        print(f"{name:14s} N={N:6d} K={K:6d} M={M}: quantize+gemm {timed(two):6.1f} us   fused {timed(one):6.1f} us", flush=True)
+        line = f"{name:14s} N={N:6d} K={K:6d} M={M}: quantize+gemm {timed(two):6.1f} us   fused {timed(one):6.1f} us"
+        if K <= 8192 and lib.mm_rmsnorm_qlinear_decode_supported(M, N, *split):
+            nw = torch.ones((K,), dtype=torch.bfloat16, device=dev)
+            def two_n():
+                lib.mm_rmsnorm_quantize(x.data_ptr(), nw.data_ptr(), 1e-5, M, K, idx.data_ptr(), *split, 0, *[pp(t) for t in a], st)
+                lib.mm_matmul(*ptrs, M, N, *split, 1, 0, None, out.data_ptr(), st)
+            one_n = lambda: lib.mm_rmsnorm_qlinear_decode(x.data_ptr(), nw.data_ptr(), 1e-5, idx.data_ptr(), *[pp(t) for t in b], M, N, *split, 1, 0, None, out.data_ptr(), st)
+            assert one_n() == 0
+            line += f"   | with RMSNorm: rmsnorm_quantize+gemm {timed(two_n):6.1f} us   fused {timed(one_n):6.1f} us"
+        print(line, flush=True)
