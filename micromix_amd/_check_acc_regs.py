@@ -20,7 +20,7 @@ def agprs(line):
     return out
 
 
-EXPECTED_KERNELS = 19   # g256w: 1; g256: 2 + 2 grouped + 1 fused gate/up + 2 persistent; g128: 2 + 2 split-K + 2 grouped + 1 fused gate/up; g64: 2 + 2 grouped
+EXPECTED_KERNELS = 16   # mx_gemm256.hip -- g256: 2 + 2 grouped + 1 fused gate/up; g128: 2 + 2 split-K + 2 grouped + 1 fused gate/up; g64: 2 + 2 grouped
 
 
 def check(asm_text):
@@ -168,29 +168,38 @@ def verify_stream(asm_text):
     return len(examined)
 
 
-def verify(asm_text):
+# tile kernels with asm-owned accumulators per translation unit (round 5: the one-wave-per-SIMD tile and the persistent kernels live in
+# files of their own)
+EXPECTED_BY_FILE = {"mx_gemm256.hip": EXPECTED_KERNELS, "mx_gemm256_w1.hip": 1, "mx_gemm256_persist.hip": 2}
+
+
+def verify(asm_text, expected=EXPECTED_KERNELS):
     """raises RuntimeError on a violation or when fewer kernels than expected were found; returns the number examined"""
     bad, examined = check_counted(asm_text)
     if bad:
         raise RuntimeError("hipcc allocated a temporary in an accumulator AGPR of a tile kernel (results would be corrupted):\n" +
                            "\n".join(f"  {s}: {c}" for s, c in bad[:10]))
-    if len(examined) < EXPECTED_KERNELS:
-        raise RuntimeError(f"accumulator-register check found {len(examined)} tile kernels, expected >= {EXPECTED_KERNELS} "
+    if len(examined) < expected:
+        raise RuntimeError(f"accumulator-register check found {len(examined)} tile kernels, expected >= {expected} "
                            "(kernel names changed? update micromix_amd/_check_acc_regs.py)")
     return len(examined)
 
 
 def main():
-    with tempfile.TemporaryDirectory() as tmp:
-        src = os.path.join(PKG, "csrc", "mx_gemm256.hip")
-        cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-fno-gpu-rdc", "-S", "--cuda-device-only",
-               src, "-o", os.path.join(tmp, "k.s")] + sys.argv[1:]
-        subprocess.run(cmd, check=True, cwd=tmp)
-        bad, examined = check_counted(open(os.path.join(tmp, "k.s")).read())
-    for sym, code in bad[:20]:
-        print(f"accumulator register used by the compiler in {sym}: {code}")
-    print(f"{len(bad)} violation(s) in {len(examined)} tile kernels with asm-owned accumulators (expected >= {EXPECTED_KERNELS})")
-    return 1 if bad or len(examined) < EXPECTED_KERNELS else 0
+    rc = 0
+    for name, expected in EXPECTED_BY_FILE.items():
+        with tempfile.TemporaryDirectory() as tmp:
+            src = os.path.join(PKG, "csrc", name)
+            cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-fno-gpu-rdc", "-S", "--cuda-device-only",
+                   src, "-o", os.path.join(tmp, "k.s")] + sys.argv[1:]
+            subprocess.run(cmd, check=True, cwd=tmp)
+            bad, examined = check_counted(open(os.path.join(tmp, "k.s")).read())
+        for sym, code in bad[:20]:
+            print(f"accumulator register used by the compiler in {sym}: {code}")
+        print(f"{name}: {len(bad)} violation(s) in {len(examined)} tile kernels with asm-owned accumulators (expected >= {expected})")
+        if bad or len(examined) < expected:
+            rc = 1
+    return rc
 
 
 if __name__ == "__main__":

@@ -22,9 +22,9 @@ OBJDIR = os.path.join(LIBDIR, "obj")
 LIB = os.path.join(LIBDIR, "libmicromix_hip.so")
 DIAG_LIB = os.path.join(LIBDIR, "libmicromix_diag.so")
 SOURCES = ["capi.hip", "reorder_quantize.hip", "direct_quantize.hip", "rmsnorm_quantize.hip", "mx_gemm.hip", "mx_gemm256.hip",
-           "mx_gemm_skinny.hip", "mx_gemm_stream.hip", "qlinear_decode.hip"]
+           "mx_gemm256_w1.hip", "mx_gemm256_persist.hip", "mx_gemm_skinny.hip", "mx_gemm_stream.hip", "qlinear_decode.hip"]
 DIAG_SOURCES = ["diag.hip"]
-HEADERS = ["mx_common.h", "mx_kernels.h", "mx_acc_regs.h", "mx_gemm_tile.inc", "mx_group_convert.h", "mx_instrument.h", "mx_direct_convert.h", "mx_decode_quant.h", "mx_rms_convert.h",
+HEADERS = ["mx_common.h", "mx_kernels.h", "mx_acc_regs.h", "mx_gemm_tile.inc", "mx_group_convert.h", "mx_instrument.h", "mx_direct_convert.h", "mx_decode_quant.h", "mx_rms_convert.h", "mx_gemm_prelude.h",
            os.path.join("..", "..", "include", "micromix_hip.h"), os.path.join("..", "..", "include", "micromix_diag.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 
@@ -57,7 +57,7 @@ def needs_build() -> bool:
 
 # sources whose kernels keep accumulators (and, in the streaming kernels, pending load destinations) in registers that only inline asm
 # names: _check_acc_regs.py examines the assembly of every build of them
-GUARDED = {"mx_gemm256.hip": "verify", "mx_gemm_stream.hip": "verify_stream"}
+GUARDED = {"mx_gemm256.hip": "verify", "mx_gemm256_w1.hip": "verify", "mx_gemm256_persist.hip": "verify", "mx_gemm_stream.hip": "verify_stream"}
 
 
 def verify_acc_regs(objdir: str = OBJDIR, src: str = "mx_gemm256.hip") -> int:
@@ -68,7 +68,10 @@ def verify_acc_regs(objdir: str = OBJDIR, src: str = "mx_gemm256.hip") -> int:
     asm = [f for f in os.listdir(objdir) if f.startswith(stem + "-") and f.endswith(".s") and "gfx950" in f]
     if not asm:
         raise RuntimeError(f"no device assembly of {src} found (was it compiled with -save-temps=obj?)")
-    return getattr(check_acc_regs, GUARDED[src])(open(os.path.join(objdir, asm[0])).read())
+    text = open(os.path.join(objdir, asm[0])).read()
+    if GUARDED[src] == "verify":
+        return check_acc_regs.verify(text, check_acc_regs.EXPECTED_BY_FILE[src])
+    return getattr(check_acc_regs, GUARDED[src])(text)
 
 
 def _flags_stamp() -> str:

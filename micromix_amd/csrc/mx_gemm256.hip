@@ -25,51 +25,10 @@
 //    fragments are already in registers.
 //  * with tokens on MFMA rows the accumulator has the feature index on the lane, so the epilogue transposes
 //    each wave's tile through LDS (free at that point) and stores whole 256-byte rows.
-#include <hip/hip_ext.h>
-#include <math.h>
-#include <stdio.h>
-#include <stdlib.h>
-#include <type_traits>
-#include <utility>
-
-#include "mx_acc_regs.h"
-#ifndef MM_FP4_KD256
-#define MM_FP4_KD256 1  // fp4 x fp4 segment on 256-deep slabs (whole cache lines per row); 0 = 128-deep slabs like the other segments
-#endif
-#ifndef MM_PRIO
-#define MM_PRIO 1        // s_setprio for waves 4-7 of the 8-wave tiles (mx_gemm_tile.inc, tile_body); 0 = none
-#endif
-#ifndef MM_XREG
-#define MM_XREG 0   // bit 0: activations of the 256-row tile's fp4 x fp4 segment through registers (mx_gemm_tile.inc, "Hybrid")
-#endif
-#include "mx_instrument.h"   // MM_DBG ablation switches and MM_CLOCKS: constant 0 unless built with -DMM_INSTRUMENT
-#ifndef MM_CHAIN
-#define MM_CHAIN 1  // chained segment hand-over on the 256-row tile (mx_gemm_tile.inc); 0 = every segment's own prologue (A/B builds)
-#endif
-#include "mx_common.h"
-#include "mx_direct_convert.h"
-#include "mx_kernels.h"
+#include "mx_gemm_prelude.h"
 
 namespace mm {
 
-// hipcc parses __device__ bodies in its host pass as well; gfx950 inline asm and target builtins only exist in
-// the device pass, so those few bodies are compiled for the device only.
-#if defined(__HIP_DEVICE_COMPILE__)
-#define MM_DEVICE_ONLY(...) __VA_ARGS__
-#else
-#define MM_DEVICE_ONLY(...)
-#endif
-
-// in-kernel split-K (split_tile_reduce): scope of the ticket atomics and cache-policy bits of the partial-sum traffic
-#define MM_SPLIT_SCOPE __HIP_MEMORY_SCOPE_AGENT
-#define MM_SPLIT_AUX 16   // sc1 = device scope
-#ifndef MM_SPLIT_FENCES
-// 1 = spell the hand-over of the in-kernel split-K with agent-scope release / acquire fences and an acq_rel ticket (split_tile_reduce).
-// Measured (round 4, tools/time_cases.py, k/v at M = 128, back-to-back launches through the Python shim, alternating processes):
-// 23.3 / 23.6 us with the fences against 16.1 / 16.4 us without -- every wave's buffer_wbl2 sc1 walks the L2 although nothing of
-// this kernel is dirty there -- so the default is 0: the same ordering from the instructions that are already needed (see there).
-#define MM_SPLIT_FENCES 0
-#endif
 #define MM_NS g256
 #define MM_MAX_STAGES 3
 #define MM_LDS_BUDGET (160 * 1024)
@@ -77,42 +36,6 @@ namespace mm {
 #define MM_TM 2
 #define MM_TN 4
 #define MM_ACC MM_ACC_CLOBBER
-#include "mx_gemm_tile.inc"
-#undef MM_NS
-#undef MM_WM
-#undef MM_TM
-#undef MM_TN
-#undef MM_ACC
-#undef MM_MAX_STAGES
-#undef MM_LDS_BUDGET
-// The 256 x 256 tile once more, for the PERSISTENT kernels only (mx_gemm_tile.inc: "Persistent launches", mm_tid): a namespace of its
-// own so that the one-tile kernels above compile exactly as before.
-#define MM_NS g256p
-#define MM_MAX_STAGES 3
-#define MM_LDS_BUDGET (160 * 1024)
-#define MM_WM 4
-#define MM_TM 2
-#define MM_TN 4
-#define MM_PERSIST_NS 1
-#define MM_ACC MM_ACC_CLOBBER
-#include "mx_gemm_tile.inc"
-#undef MM_NS
-#undef MM_WM
-#undef MM_TM
-#undef MM_TN
-#undef MM_ACC
-#undef MM_MAX_STAGES
-#undef MM_LDS_BUDGET
-// The same 256 x 256 tile with ONE wave per SIMD (round 5): 4 waves as 2 x 2, 128 x 128 outputs = 4 x 4 MFMA tiles
-// per wave, all 256 AGPRs are accumulators, 4 + 4 fragment reads per 16 MFMAs instead of 2 + 4 per 8.
-#define MM_NS g256w
-#define MM_MAX_STAGES 3
-#define MM_LDS_BUDGET (160 * 1024)
-#define MM_WM 2
-#define MM_TM 4
-#define MM_TN 4
-#define MM_W1 1
-#define MM_ACC MM_ACC_CLOBBER256
 #include "mx_gemm_tile.inc"
 #undef MM_NS
 #undef MM_WM
@@ -398,17 +321,6 @@ size_t mx_gemm_workspace_bytes(int M, int N, const int K[3], bool w4, bool force
     return (tickets_zeroed ? MM_TICKET_BYTES : 0) + tiles * S * SPLIT_WG_FLOATS * sizeof(float);
 }
 
-template <class KernelT>
-static hipError_t launch_tile(KernelT kern, DynamicLdsOnce &attr, int lds_bytes, int tiles, int threads, const GemmArgs &a,
-                              hipStream_t stream) {
-    if (hipError_t e = attr.ensure(reinterpret_cast<const void *>(kern), lds_bytes); e != hipSuccess) return e;
-    if (a.ev_start != nullptr && a.ev_stop != nullptr)
-        hipExtLaunchKernelGGL(kern, dim3(tiles), dim3(threads), lds_bytes, stream, a.ev_start, a.ev_stop, 0, a);
-    else
-        hipLaunchKernelGGL(kern, dim3(tiles), dim3(threads), lds_bytes, stream, a);
-    return hipGetLastError();
-}
-
 // Which kernel(s) a problem runs on: decided once here, used by the launcher and by mm_matmul_describe.
 enum TileKind { TK_SPLITK, TK_SMALL_SPLIT, TK_G64, TK_G256_TAIL, TK_G256, TK_G128, TK_G32, TK_G32N, TK_G16 };
 struct TilePlan {
@@ -646,9 +558,8 @@ hipError_t launch_mx_gemm256(const GemmArgs &a, bool w4, hipStream_t stream) {
             lo.n_tiles = p.tn - c;
             hi.n_tile0 = p.tn - c;
             hi.n_tiles = c;
-            static DynamicLdsOnce dpt;
             const int pg = persist_grid(p.tm256 * (p.tn - c), w4);
-            hipError_t e = pg ? launch_tile(g256p::mx_gemm256_persist_kernel<false>, dpt, g256p::LDS_BUDGET, pg, g256::NT, lo, stream)
+            hipError_t e = pg ? launch_g256p(false, lo, pg, stream)
                          : w4 ? launch_tile(g256::mx_gemm256_kernel<true, false>, done[0], g256::Lds<true>::TOTAL, p.tm256 * (p.tn - c), g256::NT, lo, stream)
                               : launch_tile(g256::mx_gemm256_kernel<false, false>, done[1], g256::Lds<false>::TOTAL, p.tm256 * (p.tn - c), g256::NT, lo, stream);
             if (e != hipSuccess) return e;
@@ -657,12 +568,10 @@ hipError_t launch_mx_gemm256(const GemmArgs &a, bool w4, hipStream_t stream) {
         }
         case TK_G256:
             if (use_w1(a.K, w4)) {
-                static DynamicLdsOnce dw1;
-                return launch_tile(g256w::mx_gemm256_kernel<true, false>, dw1, g256w::Lds<true>::TOTAL, p.tiles256, g256w::NT, a, stream);
+                return launch_g256w(a, p.tiles256, stream);
             }
             if (const int pg = persist_grid(p.tiles256, w4)) {
-                static DynamicLdsOnce dp;
-                return launch_tile(g256p::mx_gemm256_persist_kernel<false>, dp, g256p::LDS_BUDGET, pg, g256::NT, a, stream);
+                return launch_g256p(false, a, pg, stream);
             }
             if (w4) return launch_tile(g256::mx_gemm256_kernel<true, false>, done[0], g256::Lds<true>::TOTAL, p.tiles256, g256::NT, a, stream);
             return launch_tile(g256::mx_gemm256_kernel<false, false>, done[1], g256::Lds<false>::TOTAL, p.tiles256, g256::NT, a, stream);
@@ -716,16 +625,14 @@ hipError_t launch_mx_gemm_act(const GemmArgs &a, hipStream_t stream) {
         lo.n_tiles = p.tn - p.tail_cols;
         hi.n_tile0 = p.tn - p.tail_cols;
         hi.n_tiles = p.tail_cols;
-        static DynamicLdsOnce dpt;
         const int pg = persist_grid(p.tm256 * lo.n_tiles, true);
-        hipError_t e = pg ? launch_tile(g256p::mx_gemm256_persist_kernel<true>, dpt, g256p::LDS_BUDGET, pg, g256::NT, lo, stream)
+        hipError_t e = pg ? launch_g256p(true, lo, pg, stream)
                           : launch_tile(g256::mx_gemm256_act_kernel, done[0], g256::Lds<true>::TOTAL, p.tm256 * lo.n_tiles, g256::NT, lo, stream);
         if (e != hipSuccess) return e;
         return launch_tile(g128::mx_gemm256_act_kernel, done[1], g128::Lds<true>::TOTAL, p.tm128 * hi.n_tiles, g128::NT, hi, stream);
     }
     if (const int pg = persist_grid(p.tm256 * p.tn, true)) {
-        static DynamicLdsOnce dp;
-        return launch_tile(g256p::mx_gemm256_persist_kernel<true>, dp, g256p::LDS_BUDGET, pg, g256::NT, a, stream);
+        return launch_g256p(true, a, pg, stream);
     }
     return launch_tile(g256::mx_gemm256_act_kernel, done[0], g256::Lds<true>::TOTAL, p.tm256 * p.tn, g256::NT, a, stream);
 }

@@ -15,17 +15,30 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 @pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc")
 def test_compiler_leaves_the_accumulator_agprs_alone():
     """the tile kernels keep their accumulators in AGPRs that only inline asm touches; hipcc must not allocate temporaries there
-    (it did once, in a kernel that needed more than its VGPR budget: tools/check_acc_regs.py has the story)"""
+    (it did once, in a kernel that needed more than its VGPR budget: tools/check_acc_regs.py has the story).  All three translation
+    units that include mx_gemm_tile.inc, compiled side by side."""
     import check_acc_regs
-    with tempfile.TemporaryDirectory() as tmp:
-        out = os.path.join(tmp, "k.s")
-        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-fno-gpu-rdc", "-S",
-                        "--cuda-device-only", os.path.join(ROOT, "micromix_amd", "csrc", "mx_gemm256.hip"), "-o", out],
-                       check=True, cwd=tmp, stderr=subprocess.DEVNULL)
-        text = open(out).read()
-    bad, examined = check_acc_regs.check_counted(text)
-    assert len(examined) >= check_acc_regs.EXPECTED_KERNELS, examined     # the regex must have matched every tile kernel
-    assert not bad, "\n".join(f"{s}: {c}" for s, c in bad[:10])
+    from concurrent.futures import ThreadPoolExecutor
+
+    def one(item):
+        name, expected = item
+        with tempfile.TemporaryDirectory() as tmp:
+            out = os.path.join(tmp, "k.s")
+            subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-fno-gpu-rdc", "-S",
+                            "--cuda-device-only", os.path.join(ROOT, "micromix_amd", "csrc", name), "-o", out],
+                           check=True, cwd=tmp, stderr=subprocess.DEVNULL)
+            bad, examined = check_acc_regs.check_counted(open(out).read())
+        return name, expected, bad, examined
+
+    # (mx_gemm256_w1.hip and mx_gemm256_persist.hip go through the same check in every `python -m micromix_amd.build`, which
+    # __graft_entry__.build() runs; compiling them here too would add two minutes to the CPU suite.  MICROMIX_TEST_ALL_GUARDS=1 does.)
+    items = list(check_acc_regs.EXPECTED_BY_FILE.items())
+    if os.environ.get("MICROMIX_TEST_ALL_GUARDS") != "1":
+        items = items[:1]
+    with ThreadPoolExecutor(max_workers=3) as pool:
+        for name, expected, bad, examined in pool.map(one, items):
+            assert len(examined) >= expected, (name, examined)     # the regex must have matched every tile kernel
+            assert not bad, name + "\n" + "\n".join(f"{s}: {c}" for s, c in bad[:10])
 
 
 VIOLATING = ("_ZN2mm3g6417mx_gemm256_kernelILb0ELb0EEEvNS_8GemmArgsE: ; @x\n"
@@ -126,7 +139,7 @@ def test_the_stream_guard_detects_planted_violations():
 
 def test_the_build_guards_both_sources(tmp_path):
     from micromix_amd import build
-    assert set(build.GUARDED) == {"mx_gemm256.hip", "mx_gemm_stream.hip"}
+    assert set(build.GUARDED) == {"mx_gemm256.hip", "mx_gemm256_w1.hip", "mx_gemm256_persist.hip", "mx_gemm_stream.hip"}
     with pytest.raises(RuntimeError, match="no device assembly of mx_gemm_stream.hip"):
         build.verify_acc_regs(str(tmp_path), "mx_gemm_stream.hip")
     (tmp_path / "mx_gemm_stream-hip-amdgcn-amd-amdhsa-gfx950.s").write_text(STREAM_OK.replace("fixed_size 0", "fixed_size 8"))
