@@ -7,7 +7,7 @@ names an accumulator register of its kernel.  Lives in the package because micro
 import os, re, subprocess, sys, tempfile
 PKG = os.path.dirname(os.path.abspath(__file__))
 NACC = {"g256w": 256, "g256p": 128, "g256": 128, "g128": 64, "g64": 32, "g32": 0, "g32n": 0, "g16": 0}   # the 4-wave tiles leave their accumulators to the compiler
-ASM_OWN = re.compile(r"^\s*(v_mfma_scale_f32_32x32x64_f8f6f4|v_accvgpr_read_b32|v_accvgpr_write_b32)\b")
+ASM_OWN = re.compile(r"^\s*(v_mfma_scale_f32_32x32x64_f8f6f4|v_mfma_f32_32x32x16_bf16|v_accvgpr_read_b32|v_accvgpr_write_b32)\b")
 
 
 def agprs(line):

@@ -20,6 +20,9 @@
 #define MM_XREG 0   // bit 0: activations of the 256-row tile's fp4 x fp4 segment through registers (mx_gemm_tile.inc, "Hybrid")
 #endif
 #include "mx_instrument.h"   // MM_DBG ablation switches and MM_CLOCKS: constant 0 unless built with -DMM_INSTRUMENT
+#ifndef MM_ROUND_MFMA
+#define MM_ROUND_MFMA 0   // 1 = the segment-boundary rounding's expansion and write-back on the matrix pipe (mx_gemm_tile.inc: 0 .. -1.7 %, and a NaN-spreading hazard; measured, not kept); 0 = all on the VALU
+#endif
 #ifndef MM_CHAIN
 #define MM_CHAIN 1  // chained segment hand-over on the 256-row tile (mx_gemm_tile.inc); 0 = every segment's own prologue (A/B builds)
 #endif
