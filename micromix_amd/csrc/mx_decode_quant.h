@@ -32,6 +32,7 @@ struct QuantIn {
     int int_round;          // the reference's round() before the conversion (0: MM_RMS_NO_INTEGER_ROUND)
 };
 constexpr int EARLY_RL = 4;
+constexpr int EARLY_WL = 2;      // with the norm: 16-byte chunks of the weight vector per thread (K / 8 <= NT * EARLY_WL)
 
 // LDS map: [staged bf16 rows | opN | opS | opO | scale bytes]; row r of a segment at op + r * pitch, its scale bytes at
 // scales + r * Gt + (first group of the segment)
@@ -202,12 +203,12 @@ __device__ __forceinline__ LdsMap quantize_rows_early(const QuantIn &a, uint8_t 
     const uint4 *ip = reinterpret_cast<const uint4 *>(a.idx + (size_t)g * 32);
     const uint4 *grow = reinterpret_cast<const uint4 *>(a.X);
     // with the norm: [norm weights | partial sums | rvar] behind the 16-byte rounded operands (rms_bytes); one more load per thread
-    // (the launcher admits the early path with the norm only when the weight vector is at most one chunk per thread: K / 8 <= NT)
+    // (the launcher admits the early path with the norm only when the weight vector is at most EARLY_WL chunks per thread)
     constexpr bool rms = RMS;
     const int P = rms_pow2(Gt);
     uint8_t *wvec = opN + ((operand_bytes(a.M, a.K) + 15) & ~(size_t)15);
     float *part = reinterpret_cast<float *>(wvec + (size_t)Kt * 2), *rvar = part + (size_t)a.M * P;
-    dq_v4u iq[4], rq[EARLY_RL], wq = {0u, 0u, 0u, 0u};
+    dq_v4u iq[4], rq[EARLY_RL], wq[EARLY_WL] = {};
 #pragma unroll
     for (int i = 0; i < 4; ++i) iq[i] = gload16(ip + i);
 #pragma unroll
@@ -215,7 +216,13 @@ __device__ __forceinline__ LdsMap quantize_rows_early(const QuantIn &a, uint8_t 
         const int c = t + k * NT;
         rq[k] = gload16(grow + (c < chunks ? c : chunks - 1));       // (past the end: the last chunk again, not stored)
     }
-    if constexpr (rms) wq = gload16(reinterpret_cast<const uint4 *>(a.norm_w) + (t < (Kt >> 3) ? t : 0));     // (wave-uniform branch; see the wait below)
+    if constexpr (rms) {                                                                                   // (see the wait below)
+#pragma unroll
+        for (int k = 0; k < EARLY_WL; ++k) {
+            const int c = t + k * NT;
+            wq[k] = gload16(reinterpret_cast<const uint4 *>(a.norm_w) + (c < (Kt >> 3) ? c : 0));
+        }
+    }
     const bool requested = request();
     if (requested) { MM_DQ_DEVICE_ONLY(asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AFTER_LOADS) : "memory");) }
     else { MM_DQ_DEVICE_ONLY(asm volatile("s_waitcnt vmcnt(0)" ::: "memory");) }
@@ -223,13 +230,22 @@ __device__ __forceinline__ LdsMap quantize_rows_early(const QuantIn &a, uint8_t 
     for (int i = 0; i < 4; ++i) { MM_DQ_DEVICE_ONLY(asm volatile("" : "+v"(iq[i]));) }
 #pragma unroll
     for (int k = 0; k < EARLY_RL; ++k) { MM_DQ_DEVICE_ONLY(asm volatile("" : "+v"(rq[k]));) }
-    if constexpr (rms) { MM_DQ_DEVICE_ONLY(asm volatile("" : "+v"(wq));) }
+    if constexpr (rms) {
+#pragma unroll
+        for (int k = 0; k < EARLY_WL; ++k) { MM_DQ_DEVICE_ONLY(asm volatile("" : "+v"(wq[k]));) }
+    }
 #pragma unroll
     for (int k = 0; k < EARLY_RL; ++k) {
         const int c = t + k * NT;
         if (c < chunks) reinterpret_cast<dq_v4u *>(stage)[c] = rq[k];
     }
-    if constexpr (rms) if (t < (Kt >> 3)) reinterpret_cast<dq_v4u *>(wvec)[t] = wq;
+    if constexpr (rms) {
+#pragma unroll
+        for (int k = 0; k < EARLY_WL; ++k) {
+            const int c = t + k * NT;
+            if (c < (Kt >> 3)) reinterpret_cast<dq_v4u *>(wvec)[c] = wq[k];
+        }
+    }
     __syncthreads();
     if constexpr (rms) {      // as quantize_rows_to_lds: partial sums in the reference's order, the halving tree by one wave per row
         for (int u = t; u < a.M * P; u += NT) {

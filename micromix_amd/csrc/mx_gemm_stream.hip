@@ -592,7 +592,7 @@ static hipError_t launch_quant(const GemmArgs &a, dq::QuantIn qi, hipStream_t st
     qi.early = (qi.mode != 1 && rows >= (size_t)a.M && (size_t)a.M * (Kt / 32) <= 64u * NW && (size_t)a.M * (Kt / 8) <= 64u * NW * dq::EARLY_RL) ? 1 : 0;
     static const int early_on = getenv("MICROMIX_DECODE_EARLY") ? atoi(getenv("MICROMIX_DECODE_EARLY")) : 1;   // kernel-developer override
     if (!early_on) qi.early = 0;
-    if (qi.norm_w != nullptr && Kt / 8 > 64u * NW) qi.early = 0;     // with the norm the early phase loads the weight vector as one chunk per thread
+    if (qi.norm_w != nullptr && Kt / 8 > 64u * NW * dq::EARLY_WL) qi.early = 0;     // with the norm the early phase loads the weight vector as EARLY_WL chunks per thread
     const size_t qbytes = rows * Kt * 2 + ops, lds = qbytes + tail;
     if (lds > LDS_WG) return hipErrorInvalidValue;      // (every mode: the supported() predicates keep callers away from this)
     static DynamicLdsOnce once;

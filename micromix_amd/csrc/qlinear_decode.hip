@@ -374,11 +374,11 @@ int qlinear_decode_supported(int M, int N, const int K[3], bool rms) {
     // M = 1 and 2 (gate/up 10.6-12.7 -> 8.5-9.3 us, fused gate + up 18.3-19.0 -> 16.2-17.7) and ties or loses from M = 4 on
     // (every workgroup repeats the quantization: beyond ~4 rounds of workgroups -- not measured, N > 32768 -- one separate quantize launch is cheaper)
     // With the norm inside (round 5, tools/time_decode.py, K = 4096, us, rmsnorm_quantize + GEMM / one launch): every workgroup repeats
-    // the sum of squares too.  Streaming kernel: gate | up N = 28672 (F = 4 on 4 waves) M = 1 18.3 / 17.4, M = 4 18.3 / 28.2; N = 14336
+    // the sum of squares too.  Streaming kernel: gate | up N = 28672 (F = 4 on 4 waves) M = 1 18.3 / 17.4 (16.0 once the early-request phase took the norm), M = 4 18.3 / 28.2; N = 14336
     // (F = 2 on 8 waves: 105 + 24 registers, ONE workgroup per CU) M = 1 11.4 / 16.0.  First fused kernel: q | k | v M = 1 11.5 / 9.1,
     // M = 4 11.6 / 11.8; q/o M = 1 9.3 / 7.9, M = 4 9.7 / 10.5.
     if (qlinear_stream_supported(M, N, K, rms)) {
-        if (rms) return (M == 1 && (N + 31) / 32 > 2 * device_cus() && N <= 32768) ? 2 : 1;
+        if (rms) return (M <= 2 && (N + 31) / 32 > 2 * device_cus() && N <= 32768) ? 2 : 1;      // (M = 2, later in the round: 18.1 / 16.6)
         return (M <= 2 && N <= 32768) ? 2 : 1;
     }
     const int feat = decode_features(N), cus = device_cus();
