@@ -157,6 +157,30 @@ def check_stream(asm_text):
     return bad, examined
 
 
+ANY_KERNEL = re.compile(r"^(_Z\w+):[^\n]*\n(.*?)\.end_amdhsa_kernel", re.S | re.M)
+
+
+def check_pending(asm_text):
+    """(violations, kernels examined): check (3) alone -- no instruction touches the destination of a vector-memory load before an
+    s_waitcnt vmcnt that covers it -- for files whose kernels issue plain loads from inline asm with "=&v" outputs and certify them
+    with ONE counted wait (rmsnorm_quantize.hip: the ring kernel's prologue; qlinear_decode.hip: mx_decode_quant.h's early phase)"""
+    bad, examined = [], []
+    for m in ANY_KERNEL.finditer(asm_text):
+        examined.append(m.group(1))
+        bad += [(m.group(1), "reads a load destination before its s_waitcnt vmcnt: " + c) for c in pending_load_violations(m.group(2))]
+    return bad, examined
+
+
+def verify_pending(asm_text):
+    bad, examined = check_pending(asm_text)
+    if bad:
+        raise RuntimeError("a register that an asm-issued load is still writing is read before its wait (results would be corrupted):\n" +
+                           "\n".join(f"  {s}: {c}" for s, c in bad[:10]))
+    if not examined:
+        raise RuntimeError("pending-load check found no kernel")
+    return len(examined)
+
+
 def verify_stream(asm_text):
     bad, examined = check_stream(asm_text)
     if bad:

@@ -57,7 +57,8 @@ def needs_build() -> bool:
 
 # sources whose kernels keep accumulators (and, in the streaming kernels, pending load destinations) in registers that only inline asm
 # names: _check_acc_regs.py examines the assembly of every build of them
-GUARDED = {"mx_gemm256.hip": "verify", "mx_gemm256_w1.hip": "verify", "mx_gemm256_persist.hip": "verify", "mx_gemm_stream.hip": "verify_stream"}
+GUARDED = {"mx_gemm256.hip": "verify", "mx_gemm256_w1.hip": "verify", "mx_gemm256_persist.hip": "verify", "mx_gemm_stream.hip": "verify_stream",
+           "rmsnorm_quantize.hip": "verify_pending", "qlinear_decode.hip": "verify_pending"}
 
 
 def verify_acc_regs(objdir: str = OBJDIR, src: str = "mx_gemm256.hip") -> int:

@@ -139,7 +139,12 @@ def test_the_stream_guard_detects_planted_violations():
 
 def test_the_build_guards_both_sources(tmp_path):
     from micromix_amd import build
-    assert set(build.GUARDED) == {"mx_gemm256.hip", "mx_gemm256_w1.hip", "mx_gemm256_persist.hip", "mx_gemm_stream.hip"}
+    assert set(build.GUARDED) == {"mx_gemm256.hip", "mx_gemm256_w1.hip", "mx_gemm256_persist.hip", "mx_gemm_stream.hip", "rmsnorm_quantize.hip",
+                                  "qlinear_decode.hip"}
+    from micromix_amd import _check_acc_regs as c
+    planted = ("_ZN2mm28rmsnorm_quantize_ring_kernelILb1ELi3EEEvPKt: ; @x\n\tglobal_load_dwordx4 v[14:17], v[4:5], off\n"
+               "\tbuffer_load_dwordx4 v1, s[52:55], s62 offen lds\n\tv_lshlrev_b32_e32 v2, 1, v14\n\ts_waitcnt vmcnt(1)\n.end_amdhsa_kernel\n")
+    assert c.check_pending(planted)[0] and not c.check_pending(planted.replace("\tv_lshlrev_b32_e32 v2, 1, v14\n\ts_waitcnt vmcnt(1)\n", "\ts_waitcnt vmcnt(1)\n\tv_lshlrev_b32_e32 v2, 1, v14\n"))[0]
     with pytest.raises(RuntimeError, match="no device assembly of mx_gemm_stream.hip"):
         build.verify_acc_regs(str(tmp_path), "mx_gemm_stream.hip")
     (tmp_path / "mx_gemm_stream-hip-amdgcn-amd-amdhsa-gfx950.s").write_text(STREAM_OK.replace("fixed_size 0", "fixed_size 8"))
