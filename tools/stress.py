@@ -1,5 +1,5 @@
 """Randomised stress of the GEMM paths: run-to-run determinism of every path, cross-path agreement (split-K vs unsplit within
-2 bf16 ulps of the running magnitude; fused decode vs two-op bit-equal), on random shapes / splits / modes.  `python tools/stress.py [seconds]`"""
+2 bf16 ulps of the running magnitude; fused decode vs two-op bit-equal, and with the RMSNorm inside), on random shapes / splits / modes.  `python tools/stress.py [seconds]`"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -45,6 +45,14 @@ while time.time() < t_end:
     if m <= 8 and mixedgemm.qlinear_decode_supported(m, n, *split):
         y = mixedgemm.qlinear_decode(x, idx, *b, *split, bias=bias, rounding=rounding)
         ok &= torch.equal(y.float(), ref) if True else True
+    if m <= 8 and k <= 8192 and mixedgemm.rmsnorm_qlinear_decode_supported(m, n, *split):
+        # round 5: the decode launch with the RMSNorm inside against rmsnorm_quantize_x -> matmul, bit for bit
+        nw = (1.0 + 0.3 * torch.randn((k,), generator=g)).to(torch.bfloat16).to(dev)
+        ir = bool(rng.integers(0, 2))
+        qn = mixedgemm.rmsnorm_quantize_x(x, nw, 1e-5, idx, *split, integer_round=ir)
+        want = mixedgemm.matmul(qn[0], b[0], qn[1], b[1], qn[2], b[2], qn[3], b[3], qn[4], b[4], qn[5], b[5], bias=bias, rounding=rounding)
+        got = mixedgemm.rmsnorm_qlinear_decode(x, nw, 1e-5, idx, *b, *split, bias=bias, rounding=rounding, integer_round=ir)
+        ok &= torch.equal(got, want)
     cases += 1
     if not ok:
         fails += 1
