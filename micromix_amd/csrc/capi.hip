@@ -29,7 +29,7 @@ static bool split_ok(int K, int KN, int KS, int KO) {
 
 extern "C" {
 
-int mm_version(void) { return 300; /* 0.3.0: + mm_gate_up_activate(_decode), mm_down_activate_decode, mm_matmul_ws_reset (0.2.0: diagnostics moved to libmicromix_diag.so, + mm_test_function) */ }
+int mm_version(void) { return 400; /* 0.4.0: + mm_rmsnorm_qlinear_decode(_supported) (0.3.0: + mm_gate_up_activate(_decode), mm_down_activate_decode, mm_matmul_ws_reset; 0.2.0: diagnostics moved to libmicromix_diag.so, + mm_test_function) */ }
 
 const char *mm_test_function(void) { return "Hello from test_function!"; /* bindings.cpp:700 */ }
 
