@@ -60,7 +60,10 @@ SETTLE_S = 1.5
 # mixed splits of SURVEY.md section 8d (name, M, N, K, split)
 MIXED = [("q_o_2048_128_1920", 4096, 4096, 4096, (2048, 128, 1920)), ("q_o_3072_896_128", 4096, 4096, 4096, (3072, 896, 128)),
          ("q_o_all_fp4", 4096, 4096, 4096, (4096, 0, 0)), ("down_12288_1024_1024", 4096, 4096, 14336, (12288, 1024, 1024)),
-         ("gate_up_0_0_4096", 4096, 14336, 4096, (0, 0, 4096)), ("gate_up_3072_896_128", 4096, 14336, 4096, (3072, 896, 128))]
+         ("gate_up_0_0_4096", 4096, 14336, 4096, (0, 0, 4096)), ("gate_up_3072_896_128", 4096, 14336, 4096, (3072, 896, 128)),
+         # the matching-precision weight mode (bindings.cpp:74-86 -> gemm.cu:26-51 -> w6a6.cu / w8a8.cu): fp6 x fp6 at the fp4 MFMA rate,
+         # fp8 x fp8 at the fp8 rate -- the same per-precision roofline formula, weights packed by reorder_quantize_w
+         ("q_o_w_0_0_4096", 4096, 4096, 4096, (0, 0, 4096), "w"), ("q_o_w_2048_128_1920", 4096, 4096, 4096, (2048, 128, 1920), "w")]
 # the one configuration the reference publishes a number for (mgemm/README.md:34-46, formula mgemm/benchmark/mxf4f6f8_bench.cu:165-167):
 # gemm_host_tn, M = 32, N = K = 4096, MXFP6(E3M2) x MXFP4, 0.19270399 ms = 5.5720 TFLOPs on an RTX 5090 -- context, not a same-node comparison
 PUBLISHED = {"M": 32, "N": 4096, "K": 4096, "split": (0, 4096, 0), "reference_ms": 0.19270399, "reference_tflops": 5.5720,
@@ -389,15 +392,13 @@ def spawn_ranks(args, argv):
     """`python bench.py --gpus N` without a rendezvous in the environment: start the N ranks as a CHILD process
     (`python -m torch.distributed.run ... bench.py --gpus N ...`), relay rank 0's JSON line and return the child's exit code.
     The parent has not touched the GPU (torch is not even imported) and never execs."""
-    import socket
     import subprocess
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    # --standalone: torch.distributed.run picks its own free rendezvous port (a port found here by bind-then-close could be taken by
+    # another job on the box before the child binds it: ADVICE r5)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           f"--nproc-per-node={args.gpus}", os.path.abspath(__file__)] + list(argv)
     print("[bench] launching the ranks: " + " ".join(cmd), file=sys.stderr, flush=True)
     child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, cwd=ROOT)
     for line in child.stdout:
@@ -455,11 +456,13 @@ def compact_line(r, details_path=None):
                                              "gemm_w_mode_kernel_us")}
     if "llama_layer" in r:
         ll = r["llama_layer"]
+        # (since round 5 the decode figures include both RMSNorms: `norms` says so -- not comparable with the round-4 keys of the same name)
         c["llama_layer"] = {m: {"us": e["us_per_layer_graph"] if (int(m) <= 64 and e.get("us_per_layer_graph")) else e["us_per_layer_stream"],
                                 "tokens_per_s": e["tokens_per_s"], "launches": e["launches_per_layer"]}
                             for m, e in ll.get("by_rows", {}).items()}
         for m, e in ll.get("hbm", {}).items():          # decode from HBM: weight sets of several layers in rotation
             c["llama_layer"].setdefault(m, {}).update({"hbm_us": e["us_per_layer"], "hbm_frac": e["hbm_frac"]})
+        c["llama_layer"]["norms"] = "inside (M <= 8)"
         if "mlp_M4096" in ll:
             c["llama_layer"]["mlp_M4096"] = {"three_op_us": ll["mlp_M4096"]["three_op_us"], "fused_us": ll["mlp_M4096"]["fused_us"]}
     if "published_config" in r:
@@ -484,6 +487,13 @@ def compact_line(r, details_path=None):
             line = json.dumps(c, separators=(",", ":"))
             if len(line) < LINE_LIMIT:
                 break
+    if len(line) >= LINE_LIMIT:          # still too long (a large `mixed` / `tp` section): only the contract keys, `roofline` and `cpu_baseline` stay
+        for k in ("tp_mlp", "row_parallel_no_exchange", "mixed", "tp", "power", "details"):
+            c.pop(k, None)
+            line = json.dumps(c, separators=(",", ":"))
+            if len(line) < LINE_LIMIT:
+                break
+    assert len(line) < LINE_LIMIT, f"the bench line has {len(line)} bytes, the driver's record keeps {LINE_LIMIT}"
     return line
 
 
@@ -704,20 +714,21 @@ def main():
     if rank == 0 and world == 1 and not args.no_extras:
         # ---- mixed splits against their per-precision rooflines (t* = sum_seg 2*M*N*K_seg / peak(seg)) ----
         mixed = {}
-        for name, mm_, nn_, kk_, split in MIXED:
+        for name, mm_, nn_, kk_, split, *wm in MIXED:
+            w_match = bool(wm) and wm[0] == "w"
             if (mm_, nn_, kk_) == (M, N, K):
                 xs, ws, ids = x, w, idx
             else:
                 xc, wc, ic = synth_inputs(1, mm_, nn_, kk_)
                 xs, ws, ids = xc.to(dev), wc.to(dev), ic.to(dev)
             am = mixedgemm.reorder_quantize_x(xs, ids, *split)
-            bm = mixedgemm.reorder_quantize_w4(ws, ids, *split)
+            bm = (mixedgemm.reorder_quantize_w if w_match else mixedgemm.reorder_quantize_w4)(ws, ids, *split)
             om = out if (mm_, nn_) == (M, N) else torch.empty((mm_, nn_), dtype=torch.bfloat16, device=dev)
             f = lambda: mm(am, bm, om)
             settle(f, 0.4)
             # the weight mode mixedgemm.matmul derives from the tensor shapes (bindings.cpp:74): with KS = KO = 0 the S / O weights
             # compare equal (both empty) -> MM_W_MATCH, which the library runs on the fp4-weight kernels (capi.hip: weights_fp4)
-            wmode_call = 0 if (split[1] == 0 and split[2] == 0) else 1
+            wmode_call = 0 if (w_match or (split[1] == 0 and split[2] == 0)) else 1
             desc = lib.mm_matmul_describe(mm_, nn_, *split, wmode_call, 0, 0).decode()
             if " + " in desc:       # two launches (tail balancing): events around K back-to-back calls, launch gaps included
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -732,7 +743,7 @@ def main():
             tstar = roofline_time_s(mm_, nn_, split) * 1e6
             mixed[name] = {"M": mm_, "N": nn_, "K": kk_, "split": list(split), "kernel_us": round(us, 2), "kernel_us_source": how,
                            "tflops": round(2.0 * mm_ * nn_ * kk_ / us / 1e6, 1), "roofline_us": round(tstar, 2),
-                           "frac": round(tstar / us, 4), "kernel": desc}
+                           "frac": round(tstar / us, 4), "kernel": desc, "weight_mode": "w" if w_match else "w4"}
             del am, bm
         result["mixed"] = mixed
 

@@ -181,6 +181,49 @@ def verify_pending(asm_text):
     return len(examined)
 
 
+# ---------------------------------------------------------------------------------------------------------
+# EVERY kernel of EVERY product object (round 6): no scratch.  A spilled VGPR is not only slow: its reload is a
+# scratch_load, hipcc certifies it with `s_waitcnt vmcnt(0)`, and inside a K loop that drains the LDS-DMA ring once per slab -- the
+# matching-precision 256-row kernel lost 2.3x that way (124 us against 53) while every numerical test stayed green.  The tile kernels
+# also may not own static LDS: FragOfsC (mx_gemm_tile.inc) relies on the dynamic LDS starting at byte 0.
+# ---------------------------------------------------------------------------------------------------------
+TILE_KERNEL = re.compile(r"mx_gemm256_(?:grouped_|act_|persist_)?kernel")
+
+
+def check_scratch(asm_text):
+    """(violations, kernels examined): private_segment_fixed_size != 0, a dynamic stack, or scratch instructions in any kernel;
+    static LDS in a tile kernel"""
+    bad, examined = [], []
+    for m in ANY_KERNEL.finditer(asm_text):
+        sym, body = m.group(1), m.group(2)
+        examined.append(sym)
+        sm = re.search(r"\.amdhsa_private_segment_fixed_size\s+(\d+)", body)
+        if sm is None:
+            bad.append((sym, "no .amdhsa_private_segment_fixed_size directive found"))
+        elif int(sm.group(1)) != 0:
+            bad.append((sym, f"scratch: {sm.group(1)} bytes per lane (register spill)"))
+        if re.search(r"\.amdhsa_uses_dynamic_stack\s+1", body):
+            bad.append((sym, "dynamic stack"))
+        for line in body.split("\n"):
+            code = line.split(";")[0].strip()
+            if code.startswith("scratch_"):
+                bad.append((sym, "scratch instruction: " + code))
+                break
+        if TILE_KERNEL.search(sym):
+            gm = re.search(r"\.amdhsa_group_segment_fixed_size\s+(\d+)", body)
+            if gm is None or int(gm.group(1)) != 0:
+                bad.append((sym, f"static LDS in a tile kernel ({gm.group(1) if gm else '?'} bytes): the dynamic LDS no longer starts at 0"))
+    return bad, examined
+
+
+def verify_scratch(asm_text):
+    bad, examined = check_scratch(asm_text)
+    if bad:
+        raise RuntimeError("a kernel of the product library uses scratch memory (a spilled register; its reload drains the DMA queue):\n" +
+                           "\n".join(f"  {s}: {c}" for s, c in bad[:10]))
+    return len(examined)
+
+
 def verify_stream(asm_text):
     bad, examined = check_stream(asm_text)
     if bad:

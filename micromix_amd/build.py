@@ -61,6 +61,17 @@ GUARDED = {"mx_gemm256.hip": "verify", "mx_gemm256_w1.hip": "verify", "mx_gemm25
            "rmsnorm_quantize.hip": "verify_pending", "qlinear_decode.hip": "verify_pending"}
 
 
+def verify_no_scratch(objdir: str, src: str) -> int:
+    """EVERY kernel of EVERY product source: no scratch (no spilled register), no static LDS in the tile kernels.  Returns the number
+    of kernels examined (0 for a source without kernels, capi.hip); raises RuntimeError on a violation."""
+    from . import _check_acc_regs as check_acc_regs
+    stem = src.replace(".hip", "")
+    asm = [f for f in os.listdir(objdir) if f.startswith(stem + "-") and f.endswith(".s") and "gfx950" in f]
+    if not asm:
+        raise RuntimeError(f"no device assembly of {src} found (was it compiled with -save-temps=obj?)")
+    return check_acc_regs.verify_scratch(open(os.path.join(objdir, asm[0])).read())
+
+
 def verify_acc_regs(objdir: str = OBJDIR, src: str = "mx_gemm256.hip") -> int:
     """The assembly hipcc generated for a guarded source (kept by -save-temps=obj) must not touch an asm-owned register outside
     the inline asm; raises RuntimeError otherwise.  Part of every build of those files, whatever its flags."""
@@ -100,16 +111,23 @@ def build(force: bool = False, keep_temps: bool = False, verbose: bool = True, e
     def compile_one(src):
         s, obj = os.path.join(CSRC, src), os.path.join(OBJDIR, src.replace(".hip", ".o"))
         if force or _stale(obj, ht, s):
-            guarded = src in GUARDED and "-save-temps=obj" not in flags
+            product = src in SOURCES              # every product source is examined (scratch); the probes of diag.hip are not
+            guarded = product and "-save-temps=obj" not in flags
             cmd = [cc, *flags, *(["-save-temps=obj"] if guarded else []), "-c", s, "-o", obj]
             if verbose:
                 print("[micromix_amd.build]", " ".join(cmd), flush=True)
             subprocess.check_call(cmd, cwd=OBJDIR)
-            if src in GUARDED:
-                n = verify_acc_regs(OBJDIR, src)  # a violation fails the build: the library would compute wrong GEMMs
+            if product:
+                try:
+                    ns = verify_no_scratch(OBJDIR, src)   # a spilled register fails the build
+                    n = verify_acc_regs(OBJDIR, src) if src in GUARDED else 0  # a violation fails the build: the library would compute wrong GEMMs
+                except RuntimeError:
+                    if os.path.exists(obj):
+                        os.remove(obj)            # the next build compiles -- and examines -- this source again
+                    raise
                 if verbose:
-                    print(f"[micromix_amd.build] asm-owned register guard, {src}: {n} kernels clean", flush=True)
-                if guarded:                       # the temporaries were kept for the guard only
+                    print(f"[micromix_amd.build] {src}: {ns} kernels without scratch" + (f", asm-owned register guard: {n} kernels clean" if src in GUARDED else ""), flush=True)
+                if guarded:                       # the temporaries were kept for the guards only
                     stem = src.replace(".hip", "")
                     for f in os.listdir(OBJDIR):
                         if f.startswith(stem + "-") or (f.startswith(stem + ".") and f != stem + ".o"):

@@ -125,20 +125,16 @@ __device__ __forceinline__ void run_segment(v16f (&acc)[TM], const uint8_t *X, c
 
 template <bool W4, int TM>
 __device__ __forceinline__ void skinny_body(const GemmArgs &a) {
-    __shared__ float red[NW][TM][16][64];
+    // TM = 1 (two workgroups per CU at 128 registers): a finished segment's partial sums wait in LDS, not in registers -- with one
+    // accumulator set per segment alive to the end (48 registers) beside two slabs of operands the kernels spilled 2 (fp4 weights) and
+    // 17 (fp8 weights) registers to scratch.  PARK = LDS images that can hold a segment while a later one runs: two for
+    // TM = 1 (2 x 32 KB; the third segment goes from the registers into image 0 once N has been summed), none beyond the one
+    // reduction image for TM = 2 (64 KB each, one workgroup per CU, 256 registers: nothing spills there).
+    constexpr int PARK = TM == 1 ? 2 : 1;
+    __shared__ float red[PARK][NW][TM][16][64];
     const int n0 = blockIdx.x * BN;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nseg[3] = {a.K[0] >> 7, a.K[1] >> 7, a.K[2] >> 7};
-
-    v16f accN[TM], accS[TM], accO[TM];
-#pragma unroll
-    for (int t = 0; t < TM; ++t)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) accN[t][i] = accS[t][i] = accO[t][i] = 0.0f;
-
-    if (nseg[0]) run_segment<EL_FP4, EL_FP4, TM>(accN, a.X[0], a.W[0], a.SFX[0], a.SFW[0], nseg[0], a.M, a.N, n0, a.sfx_row_tiles, a.sfw_row_tiles);
-    if (nseg[1]) run_segment<EL_FP6, (W4 ? EL_FP4 : EL_FP6), TM>(accS, a.X[1], a.W[1], a.SFX[1], a.SFW[1], nseg[1], a.M, a.N, n0, a.sfx_row_tiles, a.sfw_row_tiles);
-    if (nseg[2]) run_segment<EL_FP8, (W4 ? EL_FP4 : EL_FP8), TM>(accO, a.X[2], a.W[2], a.SFX[2], a.SFW[2], nseg[2], a.M, a.N, n0, a.sfx_row_tiles, a.sfw_row_tiles);
 
     // cross-wave reduction, one segment at a time; thread `threadIdx.x` owns elements e = threadIdx.x + 512 * j of the
     // TM x 16 x 64 accumulator image and carries the running D through the reference's rounding chain
@@ -146,29 +142,62 @@ __device__ __forceinline__ void skinny_body(const GemmArgs &a) {
     float run[PER];
 #pragma unroll
     for (int j = 0; j < PER; ++j) run[j] = 0.0f;
-    bool any = false;
-    auto reduce = [&](const v16f (&acc)[TM]) {
-        __syncthreads();
+    auto park = [&](const v16f (&acc)[TM], int img) {
 #pragma unroll
         for (int t = 0; t < TM; ++t)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) red[wave][t][i][lane] = acc[t][i];
-        __syncthreads();
+            for (int i = 0; i < 16; ++i) red[img][wave][t][i][lane] = acc[t][i];
+    };
+    auto sum_image = [&](int img) {
 #pragma unroll
         for (int j = 0; j < PER; ++j) {
             const int e = threadIdx.x + NT * j;
             float s = 0.0f;
 #pragma unroll
-            for (int w = 0; w < NW; ++w) s += (&red[w][0][0][0])[e];
+            for (int w = 0; w < NW; ++w) s += (&red[img][w][0][0][0])[e];
             s += run[j];
             run[j] = a.round_per_segment ? bf16_bits_to_f32(f32_to_bf16_bits(s)) : s;
         }
-        any = true;
     };
-    if (nseg[0]) reduce(accN);
-    if (nseg[1]) reduce(accS);
-    if (nseg[2]) reduce(accO);
-    (void)any;
+    auto zero = [&](v16f (&acc)[TM]) {
+#pragma unroll
+        for (int t = 0; t < TM; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
+    };
+    if constexpr (TM == 1) {
+        v16f acc[TM];
+        // N -> image 0, S -> image 1 (each wave writes its own slots: no barrier), O stays in the registers until N has been summed
+        if (nseg[0]) { zero(acc); run_segment<EL_FP4, EL_FP4, TM>(acc, a.X[0], a.W[0], a.SFX[0], a.SFW[0], nseg[0], a.M, a.N, n0, a.sfx_row_tiles, a.sfw_row_tiles); park(acc, 0); }
+        if (nseg[1]) { zero(acc); run_segment<EL_FP6, (W4 ? EL_FP4 : EL_FP6), TM>(acc, a.X[1], a.W[1], a.SFX[1], a.SFW[1], nseg[1], a.M, a.N, n0, a.sfx_row_tiles, a.sfw_row_tiles); park(acc, 1); }
+        if (nseg[2]) { zero(acc); run_segment<EL_FP8, (W4 ? EL_FP4 : EL_FP8), TM>(acc, a.X[2], a.W[2], a.SFX[2], a.SFW[2], nseg[2], a.M, a.N, n0, a.sfx_row_tiles, a.sfw_row_tiles); }
+        __syncthreads();
+        if (nseg[0]) sum_image(0);
+        if (nseg[1]) sum_image(1);
+        if (nseg[2]) {
+            __syncthreads();          // every thread is past its reads of image 0
+            park(acc, 0);
+            __syncthreads();
+            sum_image(0);
+        }
+    } else {
+        v16f accN[TM], accS[TM], accO[TM];
+        zero(accN);
+        zero(accS);
+        zero(accO);
+        if (nseg[0]) run_segment<EL_FP4, EL_FP4, TM>(accN, a.X[0], a.W[0], a.SFX[0], a.SFW[0], nseg[0], a.M, a.N, n0, a.sfx_row_tiles, a.sfw_row_tiles);
+        if (nseg[1]) run_segment<EL_FP6, (W4 ? EL_FP4 : EL_FP6), TM>(accS, a.X[1], a.W[1], a.SFX[1], a.SFW[1], nseg[1], a.M, a.N, n0, a.sfx_row_tiles, a.sfw_row_tiles);
+        if (nseg[2]) run_segment<EL_FP8, (W4 ? EL_FP4 : EL_FP8), TM>(accO, a.X[2], a.W[2], a.SFX[2], a.SFW[2], nseg[2], a.M, a.N, n0, a.sfx_row_tiles, a.sfw_row_tiles);
+        auto reduce = [&](const v16f (&acc)[TM]) {
+            __syncthreads();
+            park(acc, 0);
+            __syncthreads();
+            sum_image(0);
+        };
+        if (nseg[0]) reduce(accN);
+        if (nseg[1]) reduce(accS);
+        if (nseg[2]) reduce(accO);
+    }
 
     // element e = (t, i, l): token row t*32 + (i & 3) + 8 * (i >> 2) + 4 * (l >> 5), feature n0 + (l & 31)
 #pragma unroll

@@ -123,9 +123,11 @@ __device__ __forceinline__ uint32_t quantize_group(const uint8_t *__restrict__ r
 // instruction covers 16 of every 32 (24) bytes: half lines, 3 us of the 11.3 of reorder_quantize at 4096 x 4096 all-fp8 (measured:
 // no stores 8.3 us; the first half only 11.9; the same bytes as fully covered write-through instructions 8.9; fully covered
 // but plain 11.6).  At most two chunks per thread: the image has at most K bytes and the workgroup at least K / 32 threads.
+// (NCH: chunks per thread; rmsnorm_quantize_kernel<*, 2> covers K bytes with K / 64 threads: four)
+template <int NCH = 2>
 __device__ __forceinline__ void store_code_image(const uint8_t *image, int bytesS, int bytesO, uint8_t *oS, uint8_t *oO, int r) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NCH; ++i) {
         const int off = (threadIdx.x + i * blockDim.x) * 16;
         if (off < bytesS + bytesO) {
             const uint4 v = *reinterpret_cast<const uint4 *>(image + off);

@@ -50,72 +50,96 @@ __device__ __forceinline__ uint32_t rms_group(const uint8_t *__restrict__ row, c
     return (uint32_t)(e + 127);
 }
 
-template <bool INT_ROUND, int MAXT>
-__global__ void __launch_bounds__(MAXT)
+// GPT = groups per thread.  8192 < K <= 16384: one (K / 32 <= 512 threads).  16384 < K <= 32768: TWO -- thread g plays the reference's group
+// threads t = g and g + 512 one after the other, with their indices and norm weights in 2 x 32 registers.  (Rounds 1-5 ran that range with
+// 1024 threads, i.e. 128 registers per lane, which this kernel does not fit in: it spilled 12-13 registers, reloaded inside the row
+// loop.  Round 6: no kernel of the library may use scratch -- 512 threads have 256 registers each.)
+template <bool INT_ROUND, int GPT>
+__global__ void __launch_bounds__(512)
 rmsnorm_quantize_kernel(const uint16_t *__restrict__ src, const uint16_t *__restrict__ weight, float eps, int rows, int K,
                         const int16_t *__restrict__ idx, int KN, int KS, int KO, uint8_t *__restrict__ oN,
                         uint8_t *__restrict__ oS, uint8_t *__restrict__ oO, uint8_t *__restrict__ sfN,
                         uint8_t *__restrict__ sfS, uint8_t *__restrict__ sfO) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];  // [K bf16 row][P floats of partial sums]
-    const int T = K >> 5;  // group threads = stager threads: thread t stages chunks t, T + t, 2T + t, 3T + t
-    const int g = threadIdx.x;
-    const bool active = g < T;
+    const int T = K >> 5;  // the reference's group threads = stager threads: group thread t stages chunks t, T + t, 2T + t, 3T + t
+    const int g = threadIdx.x, NTH = (int)blockDim.x;
+    // this thread's group threads: t_u = g + u * NTH (GPT = 1: NTH >= T, so t_0 = g alone)
+    bool active[GPT];
+#pragma unroll
+    for (int u = 0; u < GPT; ++u) active[u] = g + u * NTH < T;
     float *part = reinterpret_cast<float *>(smem + (size_t)K * 2);
     int P = 64;
     while (P < T) P <<= 1;
     const int bytesS = KS / 4 * 3;
-    uint8_t *image = smem + (size_t)K * 2 + (size_t)(P > (int)blockDim.x ? P : (int)blockDim.x) * 4;   // [row][partial sums][image of the S | O codes]
+    const int pslots = P > GPT * NTH ? P : GPT * NTH;
+    uint8_t *image = smem + (size_t)K * 2 + (size_t)pslots * 4;   // [row][partial sums][image of the S | O codes]
 
     // the norm weights of this thread's 32 columns: the weight vector is staged in LDS (coalesced) and gathered from there
     // with the same byte offsets as the row (32 scattered 2-byte global loads per thread cost more than the two rows a
     // workgroup typically processes)
-    uint32_t ix[16], wg[16];
-    if (active) {
+    uint32_t ix[GPT][16], wg[GPT][16];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            reinterpret_cast<uint4 *>(smem)[swizzle_chunk(i * T + g)] = reinterpret_cast<const uint4 *>(weight)[i * T + g];
-    }
+    for (int u = 0; u < GPT; ++u)
+        if (active[u]) {
+            const int t = g + u * NTH;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                reinterpret_cast<uint4 *>(smem)[swizzle_chunk(i * T + t)] = reinterpret_cast<const uint4 *>(weight)[i * T + t];
+        }
     __syncthreads();
-    if (active) {
-        const uint4 *p = reinterpret_cast<const uint4 *>(idx + (size_t)g * 32);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const uint4 q = p[i];
-            const uint32_t w[4] = {q.x, q.y, q.z, q.w};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const uint32_t both = swizzle_offsets((w[k] << 1) & 0xFFFEFFFEu);       // byte offsets into a staged (chunk-swizzled) [K] bf16 vector
-                const uint32_t b0 = both & 0xFFFFu, b1 = both >> 16;
-                ix[4 * i + k] = b0 | (b1 << 16);
-                wg[4 * i + k] = (uint32_t)*reinterpret_cast<const uint16_t *>(smem + b0) |
-                                ((uint32_t)*reinterpret_cast<const uint16_t *>(smem + b1) << 16);
-            }
-        }
-    }
-    __syncthreads();   // the row staging below reuses the same LDS bytes
-    const int gN = KN >> 5, gS = KS >> 5;
-    int seg, j, kseg;
-    if (g < gN) { seg = 0; j = g; kseg = KN; }
-    else if (g < gN + gS) { seg = 1; j = g - gN; kseg = KS; }
-    else { seg = 2; j = g - gN - gS; kseg = KO; }
-
-    // the next row's four chunks are loaded into registers before the current row is processed (HBM latency hides under
-    // the gather), and stored to LDS -- squares summed on the way -- after the barrier that ends the current row
-    uint4 stage[4];
-    auto fetch = [&](int r) {
-        if (active && r < rows) {
-            const uint4 *grow = reinterpret_cast<const uint4 *>(src + (size_t)r * K);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) stage[i] = grow[i * T + g];
-        }
-    };
-    auto stage_and_sum = [&]() -> float {
-        float sum = 0.0f;
-        if (active) {
+    for (int u = 0; u < GPT; ++u)
+        if (active[u]) {
+            const uint4 *p = reinterpret_cast<const uint4 *>(idx + (size_t)(g + u * NTH) * 32);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                reinterpret_cast<uint4 *>(smem)[swizzle_chunk(i * T + g)] = stage[i];
-                const uint32_t w[4] = {stage[i].x, stage[i].y, stage[i].z, stage[i].w};
+                const uint4 q = p[i];
+                const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t both = swizzle_offsets((w[k] << 1) & 0xFFFEFFFEu);       // byte offsets into a staged (chunk-swizzled) [K] bf16 vector
+                    const uint32_t b0 = both & 0xFFFFu, b1 = both >> 16;
+                    ix[u][4 * i + k] = b0 | (b1 << 16);
+                    wg[u][4 * i + k] = (uint32_t)*reinterpret_cast<const uint16_t *>(smem + b0) |
+                                       ((uint32_t)*reinterpret_cast<const uint16_t *>(smem + b1) << 16);
+                }
+            }
+        }
+    __syncthreads();   // the row staging below reuses the same LDS bytes
+    const int gN = KN >> 5, gS = KS >> 5;
+    int seg[GPT], j[GPT], kseg[GPT];
+#pragma unroll
+    for (int u = 0; u < GPT; ++u) {
+        const int t = g + u * NTH;
+        if (t < gN) { seg[u] = 0; j[u] = t; kseg[u] = KN; }
+        else if (t < gN + gS) { seg[u] = 1; j[u] = t - gN; kseg[u] = KS; }
+        else { seg[u] = 2; j[u] = t - gN - gS; kseg[u] = KO; }
+    }
+
+    // GPT = 1: the next row's four chunks are loaded into registers before the current row is processed (HBM latency hides under
+    // the gather), and stored to LDS -- squares summed on the way -- after the barrier that ends the current row.
+    // GPT = 2 fetches each row when it needs it (2 x 4 chunks: the registers go to the second group's indices and weights)
+    constexpr bool PREFETCH = GPT == 1;
+    uint4 stage[GPT][4];
+    auto fetch = [&](int r) {
+        if (r < rows) {
+            const uint4 *grow = reinterpret_cast<const uint4 *>(src + (size_t)r * K);
+#pragma unroll
+            for (int u = 0; u < GPT; ++u)
+                if (active[u]) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) stage[u][i] = grow[i * T + g + u * NTH];
+                }
+        }
+    };
+    // (the partial sum of group thread t_u, in the reference's order: its four chunks one after the other)
+    auto stage_and_sum = [&](int u) -> float {
+        float sum = 0.0f;
+        if (active[u]) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                reinterpret_cast<uint4 *>(smem)[swizzle_chunk(i * T + g + u * NTH)] = stage[u][i];
+                const uint32_t w[4] = {stage[u][i].x, stage[u][i].y, stage[u][i].z, stage[u][i].w};
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const float a = bf16_bits_to_f32(w[k] & 0xFFFFu), b = bf16_bits_to_f32(w[k] >> 16);
@@ -126,19 +150,20 @@ rmsnorm_quantize_kernel(const uint16_t *__restrict__ src, const uint16_t *__rest
         }
         return sum;
     };
-    // (the 1024-thread variant, K > 16384, has only 128 registers per lane: it fetches each row when it needs it instead
-    // of one row ahead)
-    constexpr bool PREFETCH = MAXT <= 512;
     if constexpr (PREFETCH) fetch(blockIdx.x);
     for (int r = blockIdx.x; r < rows; r += gridDim.x) {
         if constexpr (!PREFETCH) fetch(r);
-        const float sum = stage_and_sum();
+        float sum[GPT];
+#pragma unroll
+        for (int u = 0; u < GPT; ++u) sum[u] = stage_and_sum(u);
         if constexpr (PREFETCH) fetch(r + gridDim.x);
-        part[g] = sum;              // threads T.. contribute the zero padding (P < 2 * blockDim.x)
-        if (g + (int)blockDim.x < P) part[g + blockDim.x] = 0.0f;
+        // part[t] for t < T, zeros up to P (P <= 2 * GPT * NTH: group threads past T contribute the zero padding)
+#pragma unroll
+        for (int u = 0; u < GPT; ++u) part[g + u * NTH] = sum[u];
+        if (g + GPT * NTH < P) part[g + GPT * NTH] = 0.0f;
         __syncthreads();
         for (int stride = P >> 1; stride >= 64; stride >>= 1) {
-            if (g < stride) part[g] += part[g + stride];
+            if (g < stride) part[g] += part[g + stride];          // (stride <= 512 <= NTH whenever GPT = 2; GPT = 1: P <= 2 NTH)
             __syncthreads();
         }
         if (g < 64) {
@@ -149,20 +174,21 @@ rmsnorm_quantize_kernel(const uint16_t *__restrict__ src, const uint16_t *__rest
         }
         __syncthreads();
         const float rvar = part[0];
-        if (active) {
-            const uint8_t *row = smem;
-            uint32_t byte;
-            uint8_t *sf;
-            byte = rms_group<INT_ROUND, false>(row, ix, wg, rvar, seg, j, r, KN, oN, image, bytesS);
-            sf = seg == 0 ? sfN : seg == 1 ? sfS : sfO;
-            const uint32_t b1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)byte, 0x55, 0xF, 0xF, false);
-            const uint32_t b2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)byte, 0xAA, 0xF, 0xF, false);
-            const uint32_t b3 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)byte, 0xFF, 0xF, 0xF, false);
-            if ((g & 3) == 0)
-                store_scale_dword(sf + sf_offset(r, j, kseg), byte | (b1 << 8) | (b2 << 16) | (b3 << 24));
-        }
+#pragma unroll
+        for (int u = 0; u < GPT; ++u)
+            if (active[u]) {
+                const uint8_t *row = smem;
+                const uint32_t byte = rms_group<INT_ROUND, false>(row, ix[u], wg[u], rvar, seg[u], j[u], r, KN, oN, image, bytesS);
+                uint8_t *sf = seg[u] == 0 ? sfN : seg[u] == 1 ? sfS : sfO;
+                const uint32_t b1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)byte, 0x55, 0xF, 0xF, false);
+                const uint32_t b2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)byte, 0xAA, 0xF, 0xF, false);
+                const uint32_t b3 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)byte, 0xFF, 0xF, 0xF, false);
+                if ((g & 3) == 0)
+                    store_scale_dword(sf + sf_offset(r, j[u], kseg[u]), byte | (b1 << 8) | (b2 << 16) | (b3 << 24));
+            }
         __syncthreads();  // the row and part[] are rewritten by the next iteration
-        store_code_image(image, bytesS, KO, oS, oO, r);   // (read here, rewritten only after the next iteration's first barrier)
+        // (the image is read here and rewritten only after the next iteration's first barrier; at most K bytes = 2 GPT chunks per thread)
+        store_code_image<2 * GPT>(image, bytesS, KO, oS, oO, r);
     }
 }
 
@@ -484,7 +510,8 @@ hipError_t launch_rmsnorm_quantize(const void *src, const void *weight, float ep
                                    uint8_t *sfS, uint8_t *sfO, hipStream_t stream) {
     if (rows == 0) return hipSuccess;
     const int T = K / 32;
-    const int threads = (T + 63) / 64 * 64;
+    const int groups_per_thread = T > 512 ? 2 : 1;     // K > 16384: rmsnorm_quantize_kernel<*, 2>, 512 threads
+    const int threads = ((T + groups_per_thread - 1) / groups_per_thread + 63) / 64 * 64;
     int P = 64;
     while (P < T) P <<= 1;
     const bool products = threads <= 256;   // K <= 8192: the 32-bit product row (see the header)
@@ -512,15 +539,16 @@ hipError_t launch_rmsnorm_quantize(const void *src, const void *weight, float ep
                   oN, oS, oO, sfN, sfS, sfO, slot);
         return hipGetLastError();
     }
-    const size_t lds = (size_t)K * (products ? 4 : 2) + (size_t)(P > threads ? P : threads) * 4 + (size_t)KS / 4 * 3 + KO;
-    // 256 / 512 / 1024 threads: K <= 8192 / 16384 / 32768 (the 1024-thread variant is limited to 128 registers and spills a few)
+    const int pslots = P > groups_per_thread * threads ? P : groups_per_thread * threads;
+    const size_t lds = (size_t)K * (products ? 4 : 2) + (size_t)pslots * 4 + (size_t)KS / 4 * 3 + KO;
+    // 256 / 512 / 512 threads: K <= 8192 / 16384 / 32768 (beyond 16384 a thread plays two of the reference's group threads)
     auto kern = products ? (integer_round ? rmsnorm_quantize_products_kernel<true> : rmsnorm_quantize_products_kernel<false>)
-              : threads <= 512 ? (integer_round ? rmsnorm_quantize_kernel<true, 512> : rmsnorm_quantize_kernel<false, 512>)
-                               : (integer_round ? rmsnorm_quantize_kernel<true, 1024> : rmsnorm_quantize_kernel<false, 1024>);
+              : groups_per_thread == 1 ? (integer_round ? rmsnorm_quantize_kernel<true, 1> : rmsnorm_quantize_kernel<false, 1>)
+                               : (integer_round ? rmsnorm_quantize_kernel<true, 2> : rmsnorm_quantize_kernel<false, 2>);
     // K > ~21000: row + partial sums + the image of the fp6 / fp8 codes pass the default 64 KiB limit of dynamic LDS (K = 32768: 100 KiB)
     static DynamicLdsOnce attr[6];
     if (lds > 48 * 1024) {
-        const int which = (threads <= 256 ? 0 : threads <= 512 ? 1 : 2) * 2 + (integer_round ? 1 : 0);
+        const int which = (products ? 0 : groups_per_thread == 1 ? 1 : 2) * 2 + (integer_round ? 1 : 0);
         if (hipError_t e = attr[which].ensure(reinterpret_cast<const void *>(kern), 104 * 1024); e != hipSuccess) return e;
     }
     const int per_cu = OccupancyCache::get(integer_round ? 4 : 5, reinterpret_cast<const void *>(kern), threads, lds);

@@ -91,7 +91,7 @@ def test_gpus_n_without_rendezvous_launches_its_own_ranks():
         assert p.returncode == 0, p.stderr[-1500:]
         return
     assert p.returncode != 0
-    assert "launching the ranks" in p.stderr and "--nproc-per-node=2" in p.stderr and "--master-addr 127.0.0.1" in p.stderr
+    assert "launching the ranks" in p.stderr and "--nproc-per-node=2" in p.stderr and "--standalone --local-addr 127.0.0.1" in p.stderr
     assert "needs an MI355X" in p.stderr and "launch with torch.distributed.run" not in p.stderr
 
 

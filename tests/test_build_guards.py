@@ -163,3 +163,46 @@ def test_compiler_leaves_the_stream_kernels_registers_alone():
         bad, examined = c.check_stream(open(out).read())
     assert len(examined) >= c.EXPECTED_STREAM_KERNELS == 60, len(examined)
     assert not bad, "\n".join(f"{s}: {x}" for s, x in bad[:10])
+
+
+SCRATCH_OK = ("_ZN2mm4g25617mx_gemm256_kernelILb0ELb0EEEvNS_8GemmArgsE: ; @x\n"
+              "\tv_add_u32_e32 v3, v4, v5\n"
+              "\t.amdhsa_group_segment_fixed_size 0\n"
+              "\t.amdhsa_private_segment_fixed_size 0\n"
+              "\t.amdhsa_uses_dynamic_stack 0\n"
+              ".end_amdhsa_kernel\n"
+              "_ZN2mm23reorder_quantize_kernelILb1EEEvPKt: ; @y\n"
+              "\tv_add_u32_e32 v3, v4, v5\n"
+              "\t.amdhsa_group_segment_fixed_size 4096\n"
+              "\t.amdhsa_private_segment_fixed_size 0\n"
+              ".end_amdhsa_kernel\n")
+
+
+def test_the_scratch_guard_covers_every_kernel_and_detects_planted_violations(tmp_path):
+    """`g256::mx_gemm256_kernel<false,false>` shipped with one spilled VGPR whose reload drained the DMA ring inside
+    the K loop, and no guard looked.  Now every kernel of every product object fails the build on scratch (a non-zero
+    private_segment_fixed_size, a dynamic stack or a scratch instruction), and the tile kernels on static LDS."""
+    from micromix_amd import _check_acc_regs as c
+    from micromix_amd import build
+    bad, examined = c.check_scratch(SCRATCH_OK)
+    assert not bad and len(examined) == 2          # any kernel name is examined; static LDS is fine outside the tile kernels
+    planted = {
+        "spill": SCRATCH_OK.replace("private_segment_fixed_size 0", "private_segment_fixed_size 8", 1),
+        "spill in a quantizer": SCRATCH_OK[::-1].replace("0 ezis_dexif_tnemges_etavirp", "25 ezis_dexif_tnemges_etavirp", 1)[::-1],
+        "scratch instruction": SCRATCH_OK.replace("\tv_add_u32_e32 v3, v4, v5\n", "\tscratch_load_dword v1, off, off ; 4-byte Folded Reload\n", 1),
+        "dynamic stack": SCRATCH_OK.replace("uses_dynamic_stack 0", "uses_dynamic_stack 1"),
+        "static LDS in a tile kernel": SCRATCH_OK.replace("group_segment_fixed_size 0", "group_segment_fixed_size 16"),
+    }
+    for what, text in planted.items():
+        bad, _ = c.check_scratch(text)
+        assert len(bad) == 1, (what, bad)
+        with pytest.raises(RuntimeError, match="scratch"):
+            c.verify_scratch(text)
+    # the build runs it on the assembly of EVERY product source, and removes the object when it fails
+    (tmp_path / "reorder_quantize-hip-amdgcn-amd-amdhsa-gfx950.s").write_text(planted["spill in a quantizer"])
+    with pytest.raises(RuntimeError, match="register spill"):
+        build.verify_no_scratch(str(tmp_path), "reorder_quantize.hip")
+    (tmp_path / "reorder_quantize-hip-amdgcn-amd-amdhsa-gfx950.s").write_text(SCRATCH_OK)
+    assert build.verify_no_scratch(str(tmp_path), "reorder_quantize.hip") == 2
+    with pytest.raises(RuntimeError, match="no device assembly"):
+        build.verify_no_scratch(str(tmp_path), "capi.hip")
