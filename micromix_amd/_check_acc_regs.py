@@ -6,7 +6,7 @@ names an accumulator register of its kernel.  Lives in the package because micro
 `python tools/check_acc_regs.py [-DFLAG ...]` is the command-line front end (exit code 1 on a violation)."""
 import os, re, subprocess, sys, tempfile
 PKG = os.path.dirname(os.path.abspath(__file__))
-NACC = {"g256w": 256, "g256p": 128, "g256": 128, "g128": 64, "g64": 32, "g32": 0, "g32n": 0, "g16": 0}   # the 4-wave tiles leave their accumulators to the compiler
+NACC = {"g256": 128, "g128": 64, "g64": 32, "g32": 0, "g32n": 0, "g16": 0}   # the 4-wave tiles leave their accumulators to the compiler
 ASM_OWN = re.compile(r"^\s*(v_mfma_scale_f32_32x32x64_f8f6f4|v_mfma_f32_32x32x16_bf16|v_accvgpr_read_b32|v_accvgpr_write_b32)\b")
 
 
@@ -32,7 +32,7 @@ def check_counted(asm_text):
     """(violations, symbols of the kernels with asm-owned accumulators that were examined).  A caller must also require
     len(examined) >= EXPECTED_KERNELS: a name-mangling change would otherwise make the check pass with nothing examined."""
     bad, examined = [], []
-    for m in re.finditer(r"^(_ZN2mm\d(g(?:256w|256p|256|128|64|32n|32|16))(?:17|21|25)mx_gemm256_(?:grouped_|act_|persist_)?kernel\w*):[^\n]*\n(.*?)\.end_amdhsa_kernel",
+    for m in re.finditer(r"^(_ZN2mm\d(g(?:256|128|64|32n|32|16))(?:17|21|25)mx_gemm256_(?:grouped_|act_)?kernel\w*):[^\n]*\n(.*?)\.end_amdhsa_kernel",
                          asm_text, re.S | re.M):
         sym, ns, body = m.group(1), m.group(2), m.group(3)
         n = NACC[ns]
@@ -187,7 +187,7 @@ def verify_pending(asm_text):
 # matching-precision 256-row kernel lost 2.3x that way (124 us against 53) while every numerical test stayed green.  The tile kernels
 # also may not own static LDS: FragOfsC (mx_gemm_tile.inc) relies on the dynamic LDS starting at byte 0.
 # ---------------------------------------------------------------------------------------------------------
-TILE_KERNEL = re.compile(r"mx_gemm256_(?:grouped_|act_|persist_)?kernel")
+TILE_KERNEL = re.compile(r"mx_gemm256_(?:grouped_|act_)?kernel")
 
 
 def check_scratch(asm_text):
@@ -235,9 +235,8 @@ def verify_stream(asm_text):
     return len(examined)
 
 
-# tile kernels with asm-owned accumulators per translation unit (round 5: the one-wave-per-SIMD tile and the persistent kernels live in
-# files of their own)
-EXPECTED_BY_FILE = {"mx_gemm256.hip": EXPECTED_KERNELS, "mx_gemm256_w1.hip": 1, "mx_gemm256_persist.hip": 2}
+# tile kernels with asm-owned accumulators per translation unit
+EXPECTED_BY_FILE = {"mx_gemm256.hip": EXPECTED_KERNELS}
 
 
 def verify(asm_text, expected=EXPECTED_KERNELS):

@@ -439,27 +439,6 @@ bool mx_gemm_small_m_uses_tiles(int M, int N, const int K[3], bool w4, size_t ws
     return need > 0 && need <= ws_bytes;
 }
 
-// 256 x 256 tiles: the one-wave-per-SIMD kernel (g256w) instead of the 8-wave one?  fp4 weights only.  MICROMIX_GEMM_W1 = 0 never,
-// 1 always, unset: the measured rule below.
-static bool use_w1(const int K[3], bool w4) {
-    static const int pin = env_int("MICROMIX_GEMM_W1", -1);
-    if (!w4 || pin == 0) return false;
-    // A/B of round 5 (profiles/r05_w1_ab.txt): equal on the fp4 x fp4 segment (-1 %), 4-12 % slower wherever an fp6 or fp8 activation segment
-    // runs -- one wave per SIMD pays its LDS-DMA issue stalls and its own ds_read latency out of its own MFMA stream.  Never by default.
-    (void)K;
-    return pin == 1;
-}
-
-// A launch of 256 x 256 tiles with more tiles than CUs as ONE persistent round of workgroups (mx_gemm_tile.inc, "PERSIST": the next
-// tile's first slab is requested in front of the epilogue)?  fp4 weights only.  MICROMIX_GEMM_PERSIST = 0 never, 1 always when
-// tiles > CUs, unset: the measured rule.
-static int persist_grid(int tiles, bool w4) {
-    static const int pin = env_int("MICROMIX_GEMM_PERSIST", -1);
-    const int cus = device_cus() & ~7;       // a multiple of 8: a workgroup's tiles stay on one XCD's chunk of the tile order
-    if (!w4 || pin == 0 || tiles <= cus || cus < 8) return 0;
-    return pin == 1 ? cus : 0;
-}
-
 const char *describe_mx_gemm256(int M, int N, const int K[3], bool w4, size_t ws_bytes, bool force_split, bool tickets_zeroed) {
     static thread_local char buf[192];
     const TilePlan p = plan_tiles(M, N, K, w4, ws_bytes > 0, ws_bytes, force_split, tickets_zeroed);
@@ -472,15 +451,10 @@ const char *describe_mx_gemm256(int M, int N, const int K[3], bool w4, size_t ws
         case TK_G32N: snprintf(buf, sizeof(buf), "mm::g32n::mx_gemm256_kernel<%s,false> x %d workgroups (64x64 tiles)", w, p.tiles32n); break;
         case TK_G16: snprintf(buf, sizeof(buf), "mm::g16::mx_gemm256_kernel<%s,false> x %d workgroups (32x64 tiles)", w, p.tiles16); break;
         case TK_G256_TAIL:
-            if (const int pg = persist_grid(p.tm256 * (p.tn - p.tail_cols), w4))
-                snprintf(buf, sizeof(buf), "mm::g256p::mx_gemm256_persist_kernel<false> x %d persistent workgroups (%d 256x256 tiles) + mm::g128::mx_gemm256_kernel<true,false> x %d (last %d tile columns as 128x256 tiles)", pg, p.tm256 * (p.tn - p.tail_cols), p.tm128 * p.tail_cols, p.tail_cols);
-            else
-                snprintf(buf, sizeof(buf), "mm::g256::mx_gemm256_kernel<%s,false> x %d workgroups (256x256 tiles) + mm::g128::mx_gemm256_kernel<%s,false> x %d (last %d tile columns as 128x256 tiles)", w, p.tm256 * (p.tn - p.tail_cols), w, p.tm128 * p.tail_cols, p.tail_cols);
+            snprintf(buf, sizeof(buf), "mm::g256::mx_gemm256_kernel<%s,false> x %d workgroups (256x256 tiles) + mm::g128::mx_gemm256_kernel<%s,false> x %d (last %d tile columns as 128x256 tiles)", w, p.tm256 * (p.tn - p.tail_cols), w, p.tm128 * p.tail_cols, p.tail_cols);
             break;
         case TK_G256:
-            if (use_w1(K, w4)) snprintf(buf, sizeof(buf), "mm::g256w::mx_gemm256_kernel<true,false> x %d workgroups (256x256 tiles, one wave per SIMD)", p.tiles256);
-            else if (const int pg = persist_grid(p.tiles256, w4)) snprintf(buf, sizeof(buf), "mm::g256p::mx_gemm256_persist_kernel<false> x %d persistent workgroups (%d 256x256 tiles)", pg, p.tiles256);
-            else snprintf(buf, sizeof(buf), "mm::g256::mx_gemm256_kernel<%s,false> x %d workgroups (256x256 tiles)", w, p.tiles256);
+            snprintf(buf, sizeof(buf), "mm::g256::mx_gemm256_kernel<%s,false> x %d workgroups (256x256 tiles)", w, p.tiles256);
             break;
         default: snprintf(buf, sizeof(buf), "mm::g128::mx_gemm256_kernel<%s,false> x %d workgroups (128x256 tiles)", w, p.tiles128); break;
     }
@@ -558,21 +532,13 @@ hipError_t launch_mx_gemm256(const GemmArgs &a, bool w4, hipStream_t stream) {
             lo.n_tiles = p.tn - c;
             hi.n_tile0 = p.tn - c;
             hi.n_tiles = c;
-            const int pg = persist_grid(p.tm256 * (p.tn - c), w4);
-            hipError_t e = pg ? launch_g256p(false, lo, pg, stream)
-                         : w4 ? launch_tile(g256::mx_gemm256_kernel<true, false>, done[0], g256::Lds<true>::TOTAL, p.tm256 * (p.tn - c), g256::NT, lo, stream)
-                              : launch_tile(g256::mx_gemm256_kernel<false, false>, done[1], g256::Lds<false>::TOTAL, p.tm256 * (p.tn - c), g256::NT, lo, stream);
+            hipError_t e = w4 ? launch_tile(g256::mx_gemm256_kernel<true, false>, done[0], g256::Lds<true>::TOTAL, p.tm256 * (p.tn - c), g256::NT, lo, stream)
+                           : launch_tile(g256::mx_gemm256_kernel<false, false>, done[1], g256::Lds<false>::TOTAL, p.tm256 * (p.tn - c), g256::NT, lo, stream);
             if (e != hipSuccess) return e;
             return w4 ? launch_tile(g128::mx_gemm256_kernel<true, false>, done[2], g128::Lds<true>::TOTAL, p.tm128 * c, g128::NT, hi, stream)
                       : launch_tile(g128::mx_gemm256_kernel<false, false>, done[3], g128::Lds<false>::TOTAL, p.tm128 * c, g128::NT, hi, stream);
         }
         case TK_G256:
-            if (use_w1(a.K, w4)) {
-                return launch_g256w(a, p.tiles256, stream);
-            }
-            if (const int pg = persist_grid(p.tiles256, w4)) {
-                return launch_g256p(false, a, pg, stream);
-            }
             if (w4) return launch_tile(g256::mx_gemm256_kernel<true, false>, done[0], g256::Lds<true>::TOTAL, p.tiles256, g256::NT, a, stream);
             return launch_tile(g256::mx_gemm256_kernel<false, false>, done[1], g256::Lds<false>::TOTAL, p.tiles256, g256::NT, a, stream);
         default:
@@ -607,9 +573,8 @@ const char *describe_mx_gemm_act(int M, int N) {
     if (!mx_gemm_act_supported(M, N)) return "weight-streaming GEMM + mm::direct_quantize_kernel<0,true> (M <= 64)";
     const ActPlan p = plan_act(M, N);
     if (p.use128) snprintf(buf, sizeof(buf), "mm::g128::mx_gemm256_act_kernel x %d workgroups (128x256 tiles, fused silu*up + quantize)", p.tm128 * p.tn);
-    else if (p.tail_cols) snprintf(buf, sizeof(buf), "mm::g256::mx_gemm256_act_kernel x %d workgroups (256x256 tiles%s) + mm::g128::mx_gemm256_act_kernel x %d", p.tm256 * (p.tn - p.tail_cols),
-                                   persist_grid(p.tm256 * (p.tn - p.tail_cols), true) ? ", persistent" : "", p.tm128 * p.tail_cols);
-    else if (const int pg = persist_grid(p.tm256 * p.tn, true)) snprintf(buf, sizeof(buf), "mm::g256p::mx_gemm256_persist_kernel<true> x %d persistent workgroups (%d 256x256 tiles, fused silu*up + quantize)", pg, p.tm256 * p.tn);
+    else if (p.tail_cols) snprintf(buf, sizeof(buf), "mm::g256::mx_gemm256_act_kernel x %d workgroups (256x256 tiles) + mm::g128::mx_gemm256_act_kernel x %d", p.tm256 * (p.tn - p.tail_cols),
+                                   p.tm128 * p.tail_cols);
     else snprintf(buf, sizeof(buf), "mm::g256::mx_gemm256_act_kernel x %d workgroups (256x256 tiles, fused silu*up + quantize)", p.tm256 * p.tn);
     return buf;
 }
@@ -625,14 +590,9 @@ hipError_t launch_mx_gemm_act(const GemmArgs &a, hipStream_t stream) {
         lo.n_tiles = p.tn - p.tail_cols;
         hi.n_tile0 = p.tn - p.tail_cols;
         hi.n_tiles = p.tail_cols;
-        const int pg = persist_grid(p.tm256 * lo.n_tiles, true);
-        hipError_t e = pg ? launch_g256p(true, lo, pg, stream)
-                          : launch_tile(g256::mx_gemm256_act_kernel, done[0], g256::Lds<true>::TOTAL, p.tm256 * lo.n_tiles, g256::NT, lo, stream);
+        hipError_t e = launch_tile(g256::mx_gemm256_act_kernel, done[0], g256::Lds<true>::TOTAL, p.tm256 * lo.n_tiles, g256::NT, lo, stream);
         if (e != hipSuccess) return e;
         return launch_tile(g128::mx_gemm256_act_kernel, done[1], g128::Lds<true>::TOTAL, p.tm128 * hi.n_tiles, g128::NT, hi, stream);
-    }
-    if (const int pg = persist_grid(p.tm256 * p.tn, true)) {
-        return launch_g256p(true, a, pg, stream);
     }
     return launch_tile(g256::mx_gemm256_act_kernel, done[0], g256::Lds<true>::TOTAL, p.tm256 * p.tn, g256::NT, a, stream);
 }

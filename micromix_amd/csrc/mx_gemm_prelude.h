@@ -1,6 +1,4 @@
-// What every translation unit that includes mx_gemm_tile.inc needs in front of it: mx_gemm256.hip (the 8-wave and 4-wave tiles),
-// mx_gemm256_w1.hip (mm::g256w, the 256 x 256 tile with one wave per SIMD) and mx_gemm256_persist.hip (mm::g256p, the persistent
-// 256 x 256-tile kernels) -- three files so that hipcc compiles them in parallel (one file took over three minutes in round 5).
+// What a translation unit that includes mx_gemm_tile.inc needs in front of it (mx_gemm256.hip; developer probes include it too).
 #pragma once
 #include <hip/hip_ext.h>
 #include <math.h>
@@ -16,13 +14,7 @@
 #ifndef MM_PRIO
 #define MM_PRIO 1        // s_setprio for waves 4-7 of the 8-wave tiles (mx_gemm_tile.inc, tile_body); 0 = none
 #endif
-#ifndef MM_XREG
-#define MM_XREG 0   // bit 0: activations of the 256-row tile's fp4 x fp4 segment through registers (mx_gemm_tile.inc, "Hybrid")
-#endif
 #include "mx_instrument.h"   // MM_DBG ablation switches and MM_CLOCKS: constant 0 unless built with -DMM_INSTRUMENT
-#ifndef MM_ROUND_MFMA
-#define MM_ROUND_MFMA 0   // 1 = the segment-boundary rounding's expansion and write-back on the matrix pipe (mx_gemm_tile.inc: 0 .. -1.7 %, and a NaN-spreading hazard; measured, not kept); 0 = all on the VALU
-#endif
 #ifndef MM_CHAIN
 #define MM_CHAIN 1  // chained segment hand-over on the 256-row tile (mx_gemm_tile.inc); 0 = every segment's own prologue (A/B builds)
 #endif
@@ -61,9 +53,5 @@ static hipError_t launch_tile(KernelT kern, DynamicLdsOnce &attr, int lds_bytes,
         hipLaunchKernelGGL(kern, dim3(tiles), dim3(threads), lds_bytes, stream, a);
     return hipGetLastError();
 }
-
-// the two experimental tile kernels, each in a translation unit of its own
-hipError_t launch_g256w(const GemmArgs &a, int tiles, hipStream_t stream);                  // mx_gemm256_w1.hip
-hipError_t launch_g256p(bool act, const GemmArgs &a, int grid, hipStream_t stream);         // mx_gemm256_persist.hip
 
 }  // namespace mm

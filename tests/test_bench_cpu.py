@@ -95,8 +95,9 @@ def test_gpus_n_without_rendezvous_launches_its_own_ranks():
     assert "needs an MI355X" in p.stderr and "launch with torch.distributed.run" not in p.stderr
 
 
-def test_developer_switches_show_in_describe():
-    """the round-5 experimental tile kernels are selected by environment variables read once per process: a child process per switch"""
+def test_describe_names_the_product_kernels_and_ignores_retired_switches():
+    """round 6 pruned the round-5 experiments (one wave per SIMD, persistent tiles) from the product library: their environment switches
+    no longer select anything -- the describe strings name the shipped kernels whatever MICROMIX_GEMM_W1 / MICROMIX_GEMM_PERSIST say"""
     import subprocess
     code = ("import sys; sys.path.insert(0, %r)\nfrom micromix_amd import _lib\nlib = _lib.load()\n"
             "print(lib.mm_matmul_describe(4096, 4096, 2048, 128, 1920, 1, 0, 0).decode())\n"
@@ -110,9 +111,4 @@ def test_developer_switches_show_in_describe():
         return p.stdout.splitlines()
     d = run()
     assert "mm::g256::mx_gemm256_kernel<true,false> x 256" in d[0] and "g256::" in d[1] and "mx_gemm256_act_kernel x 1792" in d[2]
-    w = run(MICROMIX_GEMM_W1="1")
-    assert "mm::g256w::" in w[0] and "one wave per SIMD" in w[0]
-    q = run(MICROMIX_GEMM_PERSIST="1")
-    assert "g256::" in q[0]                                              # one round of tiles: nothing to persist
-    assert "g256p::mx_gemm256_persist_kernel<false> x 256 persistent workgroups (768 256x256 tiles)" in q[1] and "last 8 tile columns" in q[1]
-    assert "g256p::mx_gemm256_persist_kernel<true> x 256 persistent workgroups (1792 256x256 tiles" in q[2]
+    assert run(MICROMIX_GEMM_W1="1", MICROMIX_GEMM_PERSIST="1") == d

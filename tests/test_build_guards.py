@@ -15,8 +15,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 @pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc")
 def test_compiler_leaves_the_accumulator_agprs_alone():
     """the tile kernels keep their accumulators in AGPRs that only inline asm touches; hipcc must not allocate temporaries there
-    (it did once, in a kernel that needed more than its VGPR budget: tools/check_acc_regs.py has the story).  All three translation
-    units that include mx_gemm_tile.inc, compiled side by side."""
+    (it did once, in a kernel that needed more than its VGPR budget: tools/check_acc_regs.py has the story)."""
     import check_acc_regs
     from concurrent.futures import ThreadPoolExecutor
 
@@ -30,11 +29,7 @@ def test_compiler_leaves_the_accumulator_agprs_alone():
             bad, examined = check_acc_regs.check_counted(open(out).read())
         return name, expected, bad, examined
 
-    # (mx_gemm256_w1.hip and mx_gemm256_persist.hip go through the same check in every `python -m micromix_amd.build`, which
-    # __graft_entry__.build() runs; compiling them here too would add two minutes to the CPU suite.  MICROMIX_TEST_ALL_GUARDS=1 does.)
     items = list(check_acc_regs.EXPECTED_BY_FILE.items())
-    if os.environ.get("MICROMIX_TEST_ALL_GUARDS") != "1":
-        items = items[:1]
     with ThreadPoolExecutor(max_workers=3) as pool:
         for name, expected, bad, examined in pool.map(one, items):
             assert len(examined) >= expected, (name, examined)     # the regex must have matched every tile kernel
@@ -139,8 +134,8 @@ def test_the_stream_guard_detects_planted_violations():
 
 def test_the_build_guards_both_sources(tmp_path):
     from micromix_amd import build
-    assert set(build.GUARDED) == {"mx_gemm256.hip", "mx_gemm256_w1.hip", "mx_gemm256_persist.hip", "mx_gemm_stream.hip", "rmsnorm_quantize.hip",
-                                  "qlinear_decode.hip"}
+    assert set(build.GUARDED) == {"mx_gemm256.hip", "mx_gemm_stream.hip", "rmsnorm_quantize.hip", "qlinear_decode.hip"}
+    assert not any("_w1" in s or "persist" in s for s in build.SOURCES)      # round 6: the round-5 experiments are out of the product library
     from micromix_amd import _check_acc_regs as c
     planted = ("_ZN2mm28rmsnorm_quantize_ring_kernelILb1ELi3EEEvPKt: ; @x\n\tglobal_load_dwordx4 v[14:17], v[4:5], off\n"
                "\tbuffer_load_dwordx4 v1, s[52:55], s62 offen lds\n\tv_lshlrev_b32_e32 v2, 1, v14\n\ts_waitcnt vmcnt(1)\n.end_amdhsa_kernel\n")

@@ -691,31 +691,3 @@ def test_two_devices_in_one_process(dev):
     check_gemm(outs[0], qx, qw, "reference", label="two devices")
 
 
-W1_PROBE = """
-import sys, torch, hashlib
-sys.path.insert(0, %r)
-import bench
-from micromix_amd import _lib, mixedgemm
-lib = _lib.load(); dev = torch.device("cuda:0")
-x, w, idx = [t.to(dev) for t in bench.synth_inputs(3, 512, 512, 1024)]
-for split in ((1024, 0, 0), (512, 128, 384), (0, 0, 1024)):
-    a = mixedgemm.reorder_quantize_x(x, idx, *split); b = mixedgemm.reorder_quantize_w4(w, idx, *split)
-    d = mixedgemm.matmul(a[0], b[0], a[1], b[1], a[2], b[2], a[3], b[3], a[4], b[4], a[5], b[5])
-    torch.cuda.synchronize()
-    print(split, hashlib.sha1(d.cpu().view(torch.int16).numpy().tobytes()).hexdigest(), lib.mm_matmul_describe(512, 512, *split, 1, 0, 0).decode())
-"""
-
-
-def test_one_wave_per_simd_tile(dev):
-    """mm::g256w (4 waves x 128 x 128, one wave per SIMD, 256 accumulators; VERDICT r4 item 1, profiles/r05_w1_ab.txt) is a developer
-    switch read once per process: a child process pins the 256 x 256 tile with and without MICROMIX_GEMM_W1=1; every output bit must be
-    the same (same MFMA sequence per accumulator) -- and the default kernel's outputs are the ones the oracle tests above hold."""
-    import subprocess
-    outs = {}
-    for w1 in ("0", "1"):
-        env = dict(os.environ, MICROMIX_GEMM_TILE="256", MICROMIX_GEMM_W1=w1)
-        p = subprocess.run([sys.executable, "-c", W1_PROBE % ROOT], env=env, capture_output=True, text=True, timeout=600)
-        assert p.returncode == 0, p.stderr[-1500:]
-        outs[w1] = [l for l in p.stdout.splitlines() if l.startswith("(")]
-    assert len(outs["0"]) == 3 and all("g256::" in l for l in outs["0"]) and all("g256w::" in l for l in outs["1"])
-    assert [l.split()[3] for l in outs["0"]] == [l.split()[3] for l in outs["1"]]
