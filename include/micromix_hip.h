@@ -206,6 +206,10 @@ int mm_gate_up_activate_decode(const void *X_bf16, const int16_t *reorder_index,
  * (mm_downproj_quantize); wmode / flags / bias as mm_matmul.  M <= 4: mm_down_activate_decode_supported() returns 0 if the shape cannot
  * run, 1 if it can, 2 if it is expected to beat the two-launch form. */
 int mm_down_activate_decode_supported(int M, int N, int DN, int DS, int DO);
+/* ... for the weight mode the launch will run in (MM_W_FP4 / MM_W_MATCH).  The five-argument form answers for matching-precision weights,
+ * whose ring / reduction tail in LDS is the larger one (64 KB against 48 KB): what it accepts launches in either mode, but it turns away
+ * long-K shapes that fit with fp4 weights (round 6; version >= 500) */
+int mm_down_activate_decode_supported_w(int M, int N, int DN, int DS, int DO, int wmode);
 int mm_down_activate_decode(const void *GU_bf16, const uint8_t *BN, const uint8_t *BS, const uint8_t *BO, const uint8_t *SFBN, const uint8_t *SFBS,
                             const uint8_t *SFBO, int M, int N, int DN, int DS, int DO, int wmode, int flags, const void *bias_bf16, void *D_bf16,
                             mm_stream_t stream);
@@ -256,6 +260,7 @@ int mm_matmul_grouped(const mm_group *groups, int ngroups, int N, int KN, int KS
  *   X_bf16 [M, KN+KS+KO] bf16, reorder_index [K] int16, B / SFB as mm_matmul, flags MM_ROUND_*, bias optional, D [M, N] bf16
  */
 int mm_qlinear_decode_supported(int M, int N, int KN, int KS, int KO);
+int mm_qlinear_decode_supported_w(int M, int N, int KN, int KS, int KO, int wmode);      /* as mm_down_activate_decode_supported_w */
 int mm_qlinear_decode(const void *X_bf16, const int16_t *reorder_index, const uint8_t *BN, const uint8_t *BS, const uint8_t *BO,
                       const uint8_t *SFBN, const uint8_t *SFBS, const uint8_t *SFBO, int M, int N, int KN, int KS, int KO,
                       int wmode, int flags, const void *bias_bf16, void *D_bf16, mm_stream_t stream);
@@ -270,6 +275,7 @@ int mm_qlinear_decode(const void *X_bf16, const int16_t *reorder_index, const ui
  */
 #define MM_NORM_NO_INTEGER_ROUND 0x100
 int mm_rmsnorm_qlinear_decode_supported(int M, int N, int KN, int KS, int KO);
+int mm_rmsnorm_qlinear_decode_supported_w(int M, int N, int KN, int KS, int KO, int wmode);
 int mm_rmsnorm_qlinear_decode(const void *X_bf16, const void *norm_weight_bf16, float eps, const int16_t *reorder_index, const uint8_t *BN,
                               const uint8_t *BS, const uint8_t *BO, const uint8_t *SFBN, const uint8_t *SFBS, const uint8_t *SFBO, int M, int N,
                               int KN, int KS, int KO, int wmode, int flags, const void *bias_bf16, void *D_bf16, mm_stream_t stream);

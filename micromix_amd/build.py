@@ -22,7 +22,7 @@ OBJDIR = os.path.join(LIBDIR, "obj")
 LIB = os.path.join(LIBDIR, "libmicromix_hip.so")
 DIAG_LIB = os.path.join(LIBDIR, "libmicromix_diag.so")
 SOURCES = ["capi.hip", "reorder_quantize.hip", "direct_quantize.hip", "rmsnorm_quantize.hip", "mx_gemm.hip", "mx_gemm256.hip",
-           "mx_gemm_skinny.hip", "mx_gemm_stream.hip", "qlinear_decode.hip"]
+           "mx_gemm_tiles_small.hip", "mx_gemm_skinny.hip", "mx_gemm_stream.hip", "qlinear_decode.hip"]
 DIAG_SOURCES = ["diag.hip"]
 HEADERS = ["mx_common.h", "mx_kernels.h", "mx_acc_regs.h", "mx_gemm_tile.inc", "mx_group_convert.h", "mx_instrument.h", "mx_direct_convert.h", "mx_decode_quant.h", "mx_rms_convert.h", "mx_gemm_prelude.h",
            os.path.join("..", "..", "include", "micromix_hip.h"), os.path.join("..", "..", "include", "micromix_diag.h")]
@@ -57,7 +57,7 @@ def needs_build() -> bool:
 
 # sources whose kernels keep accumulators (and, in the streaming kernels, pending load destinations) in registers that only inline asm
 # names: _check_acc_regs.py examines the assembly of every build of them
-GUARDED = {"mx_gemm256.hip": "verify", "mx_gemm_stream.hip": "verify_stream",
+GUARDED = {"mx_gemm256.hip": "verify", "mx_gemm_tiles_small.hip": "verify", "mx_gemm_stream.hip": "verify_stream",
            "rmsnorm_quantize.hip": "verify_pending", "qlinear_decode.hip": "verify_pending"}
 
 

@@ -29,7 +29,7 @@ static bool split_ok(int K, int KN, int KS, int KO) {
 
 extern "C" {
 
-int mm_version(void) { return 400; /* 0.4.0: + mm_rmsnorm_qlinear_decode(_supported) (0.3.0: + mm_gate_up_activate(_decode), mm_down_activate_decode, mm_matmul_ws_reset; 0.2.0: diagnostics moved to libmicromix_diag.so, + mm_test_function) */ }
+int mm_version(void) { return 500; /* 0.5.0: + the *_supported_w queries (weight mode); 0.4.0: + mm_rmsnorm_qlinear_decode(_supported) (0.3.0: + mm_gate_up_activate(_decode), mm_down_activate_decode, mm_matmul_ws_reset; 0.2.0: diagnostics moved to libmicromix_diag.so, + mm_test_function) */ }
 
 const char *mm_test_function(void) { return "Hello from test_function!"; /* bindings.cpp:700 */ }
 
@@ -113,11 +113,15 @@ int mm_rmsnorm_quantize(const void *X_bf16, const void *W_bf16, float eps, int r
     return e == hipSuccess ? MM_OK : fail_hip(e, "mm_rmsnorm_quantize");
 }
 
-int mm_qlinear_decode_supported(int M, int N, int KN, int KS, int KO) {
+// (the five-argument queries answer for the matching-precision weight mode, whose ring / reduction tail is the larger one: what they
+// accept launches in either mode; the _w forms take the weight mode and accept the long-K fp4 shapes the 48 KB tail leaves room for)
+int mm_qlinear_decode_supported_w(int M, int N, int KN, int KS, int KO, int wmode) {
     if (N < 0 || KN < 0 || KS < 0 || KO < 0 || (KN % 128) || (KS % 128) || (KO % 128) || KN + KS + KO == 0 || KN + KS + KO > 32768) return 0;
+    if (wmode != MM_W_MATCH && wmode != MM_W_FP4) return 0;
     const int K[3] = {KN, KS, KO};
-    return mm::qlinear_decode_supported(M, N, K);
+    return mm::qlinear_decode_supported(M, N, K, false, weights_fp4(wmode, KS, KO));
 }
+int mm_qlinear_decode_supported(int M, int N, int KN, int KS, int KO) { return mm_qlinear_decode_supported_w(M, N, KN, KS, KO, (KS | KO) ? MM_W_MATCH : MM_W_FP4); }
 
 int mm_qlinear_decode(const void *X_bf16, const int16_t *reorder_index, const uint8_t *BN, const uint8_t *BS, const uint8_t *BO,
                       const uint8_t *SFBN, const uint8_t *SFBS, const uint8_t *SFBO, int M, int N, int KN, int KS, int KO,
@@ -127,7 +131,7 @@ int mm_qlinear_decode(const void *X_bf16, const int16_t *reorder_index, const ui
     if (wmode != MM_W_MATCH && wmode != MM_W_FP4) return MM_ERR_BAD_ARG;
     if (flags & MM_OUT_F32) return MM_ERR_UNSUPPORTED;    // fp32 partial sums come from mm_matmul only
     if (M == 0 || N == 0) return MM_OK;
-    if (!mm_qlinear_decode_supported(M, N, KN, KS, KO)) return MM_ERR_UNSUPPORTED;
+    if (!mm_qlinear_decode_supported_w(M, N, KN, KS, KO, wmode)) return MM_ERR_UNSUPPORTED;
     if (!X_bf16 || !reorder_index || !D_bf16) return MM_ERR_BAD_ARG;
     if ((KN && (!BN || !SFBN)) || (KS && (!BS || !SFBS)) || (KO && (!BO || !SFBO))) return MM_ERR_BAD_ARG;
     const uint8_t *W[3] = {BN, BS, BO}, *SFW[3] = {SFBN, SFBS, SFBO};
@@ -137,11 +141,13 @@ int mm_qlinear_decode(const void *X_bf16, const int16_t *reorder_index, const ui
     return e == hipSuccess ? MM_OK : fail_hip(e, "mm_qlinear_decode");
 }
 
-int mm_rmsnorm_qlinear_decode_supported(int M, int N, int KN, int KS, int KO) {
+int mm_rmsnorm_qlinear_decode_supported_w(int M, int N, int KN, int KS, int KO, int wmode) {
     if (N < 0 || KN < 0 || KS < 0 || KO < 0 || (KN % 128) || (KS % 128) || (KO % 128) || KN + KS + KO == 0 || KN + KS + KO > 32768) return 0;
+    if (wmode != MM_W_MATCH && wmode != MM_W_FP4) return 0;
     const int K[3] = {KN, KS, KO};
-    return mm::qlinear_decode_supported(M, N, K, true);
+    return mm::qlinear_decode_supported(M, N, K, true, weights_fp4(wmode, KS, KO));
 }
+int mm_rmsnorm_qlinear_decode_supported(int M, int N, int KN, int KS, int KO) { return mm_rmsnorm_qlinear_decode_supported_w(M, N, KN, KS, KO, (KS | KO) ? MM_W_MATCH : MM_W_FP4); }
 
 int mm_rmsnorm_qlinear_decode(const void *X_bf16, const void *norm_weight_bf16, float eps, const int16_t *reorder_index, const uint8_t *BN,
                               const uint8_t *BS, const uint8_t *BO, const uint8_t *SFBN, const uint8_t *SFBS, const uint8_t *SFBO, int M, int N,
@@ -151,7 +157,7 @@ int mm_rmsnorm_qlinear_decode(const void *X_bf16, const void *norm_weight_bf16, 
     if (wmode != MM_W_MATCH && wmode != MM_W_FP4) return MM_ERR_BAD_ARG;
     if (flags & ~(MM_ROUND_ONCE | MM_NORM_NO_INTEGER_ROUND)) return MM_ERR_BAD_ARG;
     if (M == 0 || N == 0) return MM_OK;
-    if (!mm_rmsnorm_qlinear_decode_supported(M, N, KN, KS, KO)) return MM_ERR_UNSUPPORTED;
+    if (!mm_rmsnorm_qlinear_decode_supported_w(M, N, KN, KS, KO, wmode)) return MM_ERR_UNSUPPORTED;
     if (!X_bf16 || !norm_weight_bf16 || !reorder_index || !D_bf16) return MM_ERR_BAD_ARG;
     if (((uintptr_t)X_bf16 & 15) || ((uintptr_t)norm_weight_bf16 & 15)) return MM_ERR_BAD_ARG;      // rows and weights are staged in 16-byte pieces
     if ((KN && (!BN || !SFBN)) || (KS && (!BS || !SFBS)) || (KO && (!BO || !SFBO))) return MM_ERR_BAD_ARG;
@@ -314,7 +320,7 @@ int mm_gate_up_activate_decode(const void *X_bf16, const int16_t *reorder_index,
     if (flags & ~MM_ROUND_ONCE) return MM_ERR_BAD_ARG;
     if (M == 0) return MM_OK;
     const int N = 2 * I;
-    if (!mm_qlinear_decode_supported(M, N, KN, KS, KO)) return MM_ERR_UNSUPPORTED;
+    if (!mm_qlinear_decode_supported_w(M, N, KN, KS, KO, MM_W_FP4)) return MM_ERR_UNSUPPORTED;
     if ((DN && (!oN || !sfN)) || (DS && (!oS || !sfS)) || (DO && (!oO || !sfO))) return MM_ERR_BAD_ARG;
     if (!workspace || workspace_bytes < (size_t)M * N * sizeof(uint16_t) || ((uintptr_t)workspace & 15)) return MM_ERR_BAD_ARG;
     // quantize + gate | up GEMM in one launch into the scratch (columns alternate 128 gate | 128 up), then the activation quantizer on
@@ -326,12 +332,14 @@ int mm_gate_up_activate_decode(const void *X_bf16, const int16_t *reorder_index,
     return e == hipSuccess ? MM_OK : fail_hip(e, "mm_gate_up_activate_decode");
 }
 
-int mm_down_activate_decode_supported(int M, int N, int DN, int DS, int DO) {
+int mm_down_activate_decode_supported_w(int M, int N, int DN, int DS, int DO, int wmode) {
     if (M < 1 || N < 1 || DN < 0 || DS < 0 || DO < 0 || (DN % 128) || (DS % 128) || (DO % 128) || DN + DS + DO == 0) return 0;
+    if (wmode != MM_W_MATCH && wmode != MM_W_FP4) return 0;
     const int K[3] = {DN, DS, DO};
-    if (!mm::down_activate_stream_supported(M, N, K)) return 0;
+    if (!mm::down_activate_stream_supported(M, N, K, weights_fp4(wmode, DS, DO))) return 0;
     return M <= 2 ? 2 : 1;      // every workgroup repeats silu * up + the quantization: one pass of its threads up to M = 2 at I = 14336
 }
+int mm_down_activate_decode_supported(int M, int N, int DN, int DS, int DO) { return mm_down_activate_decode_supported_w(M, N, DN, DS, DO, (DS | DO) ? MM_W_MATCH : MM_W_FP4); }
 
 int mm_down_activate_decode(const void *GU_bf16, const uint8_t *BN, const uint8_t *BS, const uint8_t *BO, const uint8_t *SFBN, const uint8_t *SFBS,
                             const uint8_t *SFBO, int M, int N, int DN, int DS, int DO, int wmode, int flags, const void *bias_bf16, void *D_bf16,
@@ -341,7 +349,7 @@ int mm_down_activate_decode(const void *GU_bf16, const uint8_t *BN, const uint8_
     if (wmode != MM_W_MATCH && wmode != MM_W_FP4) return MM_ERR_BAD_ARG;
     if (flags & ~MM_ROUND_ONCE) return MM_ERR_BAD_ARG;
     if (M == 0 || N == 0) return MM_OK;
-    if (!mm_down_activate_decode_supported(M, N, DN, DS, DO)) return MM_ERR_UNSUPPORTED;
+    if (!mm_down_activate_decode_supported_w(M, N, DN, DS, DO, wmode)) return MM_ERR_UNSUPPORTED;
     if (!GU_bf16 || !D_bf16 || ((uintptr_t)GU_bf16 & 15)) return MM_ERR_BAD_ARG;
     if ((DN && (!BN || !SFBN)) || (DS && (!BS || !SFBS)) || (DO && (!BO || !SFBO))) return MM_ERR_BAD_ARG;
     const uint8_t *W[3] = {BN, BS, BO}, *SFW[3] = {SFBN, SFBS, SFBO};

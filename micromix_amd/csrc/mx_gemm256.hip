@@ -30,7 +30,11 @@
 namespace mm {
 
 #define MM_NS g256
+#ifdef MM_G256_MAX_STAGES          // developer probe (tools/delivery_probes.sh): the 256-row tile's 128-deep segments on two stages
+#define MM_MAX_STAGES MM_G256_MAX_STAGES
+#else
 #define MM_MAX_STAGES 3
+#endif
 #define MM_LDS_BUDGET (160 * 1024)
 #define MM_WM 4
 #define MM_TM 2
@@ -59,67 +63,6 @@ namespace mm {
 #undef MM_ACC
 #undef MM_MAX_STAGES
 #undef MM_LDS_BUDGET
-#define MM_NS g64
-#define MM_MAX_STAGES 3
-#define MM_LDS_BUDGET (160 * 1024)
-#define MM_WM 4
-#define MM_TM 1
-#define MM_TN 2
-#define MM_ACC MM_ACC_CLOBBER
-#include "mx_gemm_tile.inc"
-#undef MM_NS
-#undef MM_WM
-#undef MM_TM
-#undef MM_TN
-#undef MM_ACC
-#undef MM_MAX_STAGES
-#undef MM_LDS_BUDGET
-#define MM_NS g32
-#define MM_MAX_STAGES 3
-#define MM_LDS_BUDGET (160 * 1024)
-#define MM_WM 2
-#define MM_TM 1
-#define MM_TN 2
-#define MM_ACC MM_ACC_CLOBBER32
-#include "mx_gemm_tile.inc"
-#undef MM_NS
-#undef MM_WM
-#undef MM_TM
-#undef MM_TN
-#undef MM_ACC
-#undef MM_MAX_STAGES
-#undef MM_LDS_BUDGET
-#define MM_NS g32n
-#define MM_MAX_STAGES 3
-#define MM_LDS_BUDGET (160 * 1024)
-#define MM_WM 2
-#define MM_TM 1
-#define MM_TN 1
-#define MM_ACC MM_ACC_CLOBBER32
-#include "mx_gemm_tile.inc"
-#undef MM_NS
-#undef MM_WM
-#undef MM_TM
-#undef MM_TN
-#undef MM_ACC
-#undef MM_MAX_STAGES
-#undef MM_LDS_BUDGET
-#define MM_NS g16
-#define MM_MAX_STAGES 3
-#define MM_LDS_BUDGET (160 * 1024)
-#define MM_WM 1
-#define MM_TM 1
-#define MM_TN 1
-#define MM_ACC MM_ACC_CLOBBER32
-#include "mx_gemm_tile.inc"
-#undef MM_NS
-#undef MM_WM
-#undef MM_TM
-#undef MM_TN
-#undef MM_ACC
-#undef MM_MAX_STAGES
-#undef MM_LDS_BUDGET
-
 
 // ---------------------------------------------------------------------------------------------------------
 // split-K for shapes with few tiles (medium M, or small N): 128 x 256 tiles x `splits` workgroups, each on a slab range
@@ -271,7 +214,7 @@ struct SmallSplit {
     int splits;
     int tiles;
 };
-constexpr size_t small_part_bytes(int kind) { return kind == 33 ? (size_t)g32n::NACC * g32n::NT * 4 : (size_t)g32::NACC * g32::NT * 4; }
+constexpr size_t small_part_bytes(int kind) { return kind == 33 ? SMALL_PART_BYTES_64x64 : SMALL_PART_BYTES_64x128; }   // (mx_gemm_prelude.h; asserted in mx_gemm_tiles_small.hip)
 constexpr size_t MM_TICKET_BYTES = 4096;   // = mm_matmul_ticket_bytes(): room for 1024 tiles (a launch of this kind has at most CUs / 2)
 static size_t small_ticket_bytes(int) { return MM_TICKET_BYTES; }
 // a split leaves one partial sum per segment it touches: at most splits + 2 slots per tile
@@ -503,28 +446,12 @@ hipError_t launch_mx_gemm256(const GemmArgs &a, bool w4, hipStream_t stream) {
                 }
                 b.split_slot[S] = (unsigned short)slot;
             }
-            const int wgs = p.small.tiles * p.small.splits;
-            static DynamicLdsOnce sdone[4];
-            if (p.small.kind == 33)
-                return w4 ? launch_tile(g32n::mx_gemm256_kernel<true, true>, sdone[0], g32n::Lds<true>::TOTAL, wgs, g32n::NTHREADS, b, stream)
-                          : launch_tile(g32n::mx_gemm256_kernel<false, true>, sdone[1], g32n::Lds<false>::TOTAL, wgs, g32n::NTHREADS, b, stream);
-            return w4 ? launch_tile(g32::mx_gemm256_kernel<true, true>, sdone[2], g32::Lds<true>::TOTAL, wgs, g32::NTHREADS, b, stream)
-                      : launch_tile(g32::mx_gemm256_kernel<false, true>, sdone[3], g32::Lds<false>::TOTAL, wgs, g32::NTHREADS, b, stream);
+            return launch_small_tile(p.small.kind, w4, true, p.small.tiles * p.small.splits, b, stream);
         }
-        case TK_G64:
-            if (w4) return launch_tile(g64::mx_gemm256_kernel<true, false>, done[6], g64::Lds<true>::TOTAL, p.tiles64, g64::NT, a, stream);
-            return launch_tile(g64::mx_gemm256_kernel<false, false>, done[7], g64::Lds<false>::TOTAL, p.tiles64, g64::NT, a, stream);
-        case TK_G32:
-            if (w4) return launch_tile(g32::mx_gemm256_kernel<true, false>, done[8], g32::Lds<true>::TOTAL, p.tiles32, g32::NTHREADS, a, stream);
-            return launch_tile(g32::mx_gemm256_kernel<false, false>, done[9], g32::Lds<false>::TOTAL, p.tiles32, g32::NTHREADS, a, stream);
-        case TK_G32N:
-            if (w4) return launch_tile(g32n::mx_gemm256_kernel<true, false>, done[10], g32n::Lds<true>::TOTAL, p.tiles32n, g32n::NTHREADS, a, stream);
-            return launch_tile(g32n::mx_gemm256_kernel<false, false>, done[11], g32n::Lds<false>::TOTAL, p.tiles32n, g32n::NTHREADS, a, stream);
-        case TK_G16: {
-            static DynamicLdsOnce d16[2];
-            if (w4) return launch_tile(g16::mx_gemm256_kernel<true, false>, d16[0], g16::Lds<true>::TOTAL, p.tiles16, g16::NTHREADS, a, stream);
-            return launch_tile(g16::mx_gemm256_kernel<false, false>, d16[1], g16::Lds<false>::TOTAL, p.tiles16, g16::NTHREADS, a, stream);
-        }
+        case TK_G64: return launch_small_tile(64, w4, false, p.tiles64, a, stream);
+        case TK_G32: return launch_small_tile(32, w4, false, p.tiles32, a, stream);
+        case TK_G32N: return launch_small_tile(33, w4, false, p.tiles32n, a, stream);
+        case TK_G16: return launch_small_tile(16, w4, false, p.tiles16, a, stream);
         case TK_G256_TAIL: {
             const int c = p.tail_cols;
             GemmArgs lo = a, hi = a;
@@ -626,16 +553,12 @@ hipError_t launch_mx_gemm256_grouped(GroupedTileArgs &ga, bool w4, hipStream_t s
         hipLaunchKernelGGL(kern, dim3(total), dim3(threads), lds, stream, ga);
         return hipGetLastError();
     };
-    if (bm == 64 && bn == 64) return w4 ? go(g32n::mx_gemm256_grouped_kernel<true>, done[6], g32n::Lds<true>::TOTAL, g32n::NTHREADS)
-                                        : go(g32n::mx_gemm256_grouped_kernel<false>, done[7], g32n::Lds<false>::TOTAL, g32n::NTHREADS);
-    if (bm == 64) return w4 ? go(g32::mx_gemm256_grouped_kernel<true>, done[8], g32::Lds<true>::TOTAL, g32::NTHREADS)
-                            : go(g32::mx_gemm256_grouped_kernel<false>, done[9], g32::Lds<false>::TOTAL, g32::NTHREADS);
+    if (bm == 64) return launch_small_tile_grouped(bn == 64 ? 33 : 32, w4, total, ga, stream);
     if (bm == 256) return w4 ? go(g256::mx_gemm256_grouped_kernel<true>, done[0], g256::Lds<true>::TOTAL, g256::NT)
                              : go(g256::mx_gemm256_grouped_kernel<false>, done[1], g256::Lds<false>::TOTAL, g256::NT);
     if (bn == 256) return w4 ? go(g128::mx_gemm256_grouped_kernel<true>, done[2], g128::Lds<true>::TOTAL, g128::NT)
                              : go(g128::mx_gemm256_grouped_kernel<false>, done[3], g128::Lds<false>::TOTAL, g128::NT);
-    return w4 ? go(g64::mx_gemm256_grouped_kernel<true>, done[4], g64::Lds<true>::TOTAL, g64::NT)
-              : go(g64::mx_gemm256_grouped_kernel<false>, done[5], g64::Lds<false>::TOTAL, g64::NT);
+    return launch_small_tile_grouped(64, w4, total, ga, stream);
 }
 
 }  // namespace mm

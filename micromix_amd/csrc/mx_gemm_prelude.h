@@ -54,4 +54,9 @@ static hipError_t launch_tile(KernelT kern, DynamicLdsOnce &attr, int lds_bytes,
     return hipGetLastError();
 }
 
+// the tiles for launches with few tiles live in mx_gemm_tiles_small.hip (compiled beside mx_gemm256.hip)
+hipError_t launch_small_tile(int kind, bool w4, bool splitk, int wgs, const GemmArgs &a, hipStream_t stream);
+hipError_t launch_small_tile_grouped(int kind, bool w4, int total, const GroupedTileArgs &ga, hipStream_t stream);
+constexpr size_t SMALL_PART_BYTES_64x64 = 16 * 256 * 4, SMALL_PART_BYTES_64x128 = 32 * 256 * 4;   // fp32 accumulators of one workgroup (in-kernel split-K)
+
 }  // namespace mm

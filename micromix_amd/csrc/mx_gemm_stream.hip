@@ -648,10 +648,10 @@ bool mx_gemm_stream_supported(int M, int N, const int K[3], bool w4) {
 // instantiations launch_quant is called with -- matching-precision weights, NW * D * SLOT = 8 * 2 * 4096 = 4 * 2 * 8192 = 8 * 4 * 2048
 // = 64 KB (fp4 weights: 48 KB).  The supported() predicates budget this worst case so that a shape they accept always launches
 // (they budgeted 48 KB whatever the weight mode).
-constexpr size_t STREAM_TAIL_BUDGET = 64 * 1024;
+constexpr size_t stream_tail_budget(bool w4) { return (w4 ? 48 : 64) * 1024; }
 
 // 1 if mm_qlinear_decode can run on the streaming kernel (the quantized rows, one staged row and the rings fit a workgroup's LDS)
-bool qlinear_stream_supported(int M, int N, const int K[3], bool rms) {
+bool qlinear_stream_supported(int M, int N, const int K[3], bool rms, bool w4) {
     static const int on = getenv("MICROMIX_DECODE_STREAM") ? atoi(getenv("MICROMIX_DECODE_STREAM")) : 1;   // kernel-developer override
     // Measured against the first fused kernel (qlinear_decode.hip; tools/time_decode.py, profiles/r04_stream_ablation.txt section 8):
     // it wins where N / 32 fills the CUs and one pass quantizes the rows (gate/up at M = 1 / 2 / 4: 12.5 / 11.8 / 14.3 -> 10.2 / 9.2 /
@@ -659,9 +659,9 @@ bool qlinear_stream_supported(int M, int N, const int K[3], bool rms) {
     const size_t Kt = (size_t)K[0] + K[1] + K[2];
     const size_t norm = rms ? dq::rms_bytes(M, K) : 0;
     if (rms && Kt > (size_t)dq::RMS_MAX_K) return false;
-    if (on == 2 && M >= 1 && M <= 8) return dq::operand_bytes(M, K) + norm + Kt * 2 + STREAM_TAIL_BUDGET + 64 <= 156 * 1024;     // (A/B runs: every shape that fits)
+    if (on == 2 && M >= 1 && M <= 8) return dq::operand_bytes(M, K) + norm + Kt * 2 + stream_tail_budget(w4) + 64 <= 156 * 1024;     // (A/B runs: every shape that fits)
     if (!on || M < 1 || M > 4 || (N + 31) / 32 < device_cus()) return false;
-    return dq::operand_bytes(M, K) + norm + Kt * 2 + STREAM_TAIL_BUDGET + 64 <= 156 * 1024;
+    return dq::operand_bytes(M, K) + norm + Kt * 2 + stream_tail_budget(w4) + 64 <= 156 * 1024;
 }
 
 hipError_t launch_qlinear_stream(const void *X, const int16_t *idx, const uint8_t *const W[3], const uint8_t *const SFW[3], int M, int N,
@@ -689,14 +689,17 @@ hipError_t launch_qlinear_stream(const void *X, const int16_t *idx, const uint8_
     a.bias = (const uint16_t *)bias;
     a.D = (uint16_t *)D;
     const bool wide = (N + 31) / 32 >= device_cus();
-    static const int qf4 = getenv("MICROMIX_DECODE_F4") ? atoi(getenv("MICROMIX_DECODE_F4")) : 0;          // kernel-developer override: 64 features x 4 waves, this many slots (-1: never)
+    // kernel-developer overrides: 64 features x 4 waves with this many slots (-1: never) / ring slots (2, 3, 4).  Ignored with the norm inside
+    // the launch: only the default (F, D, NW) configurations have norm variants (an override made a supported shape fail at launch)
+    static const int qf4_env = getenv("MICROMIX_DECODE_F4") ? atoi(getenv("MICROMIX_DECODE_F4")) : 0;
+    static const int qd_env = getenv("MICROMIX_DECODE_DEPTH") ? atoi(getenv("MICROMIX_DECODE_DEPTH")) : 2;
+    const int qf4 = norm.weight != nullptr ? 0 : qf4_env, qd = norm.weight != nullptr ? 2 : qd_env;
     if (wide && qf4 == 2) return w4 ? launch_quant<4, 2, 4, true>(a, qi, stream) : launch_quant<4, 2, 4, false>(a, qi, stream);
     if (wide && qf4 == 3) return w4 ? launch_quant<4, 3, 4, true>(a, qi, stream) : launch_quant<4, 3, 4, false>(a, qi, stream);
     if (wide && qf4 == 4) return w4 ? launch_quant<4, 4, 4, true>(a, qi, stream) : launch_quant<4, 4, 4, false>(a, qi, stream);
     // more than one round of 32-feature workgroups (two per CU): 64 features x 4 waves halve the workgroups that repeat the quantization and
     // run in one round (fused gate + up, N = 28672, M = 1: 17.3 -> 14.2 us, from HBM 18.7 -> 16.1; at N = 14336 it loses 1 us from HBM)
     if (wide && qf4 == 0 && (N + 31) / 32 > 2 * device_cus()) return w4 ? launch_quant<4, 2, 4, true>(a, qi, stream) : launch_quant<4, 2, 4, false>(a, qi, stream);
-    static const int qd = getenv("MICROMIX_DECODE_DEPTH") ? atoi(getenv("MICROMIX_DECODE_DEPTH")) : 2;     // kernel-developer override: ring slots (2, 3, 4)
     if (wide && qd == 3) return w4 ? launch_quant<2, 3, 8, true>(a, qi, stream) : launch_quant<2, 3, 8, false>(a, qi, stream);
     if (wide && qd == 4) return w4 ? launch_quant<2, 4, 8, true>(a, qi, stream) : launch_quant<2, 4, 8, false>(a, qi, stream);
     if (wide) return w4 ? launch_quant<2, 2, 8, true>(a, qi, stream) : launch_quant<2, 2, 8, false>(a, qi, stream);
@@ -706,9 +709,9 @@ hipError_t launch_qlinear_stream(const void *X, const int16_t *idx, const uint8_
 
 // mm_down_activate_decode: down_proj at M <= 4 straight from the bf16 gate | up matrix -- every workgroup computes silu(gate) * up and
 // quantizes it for its own use (the bytes of mm_activate_quantize), K = the intermediate size in natural order
-bool down_activate_stream_supported(int M, int N, const int K[3]) {
+bool down_activate_stream_supported(int M, int N, const int K[3], bool w4) {
     (void)N;
-    return M >= 1 && M <= 4 && dq::operand_bytes(M, K) + STREAM_TAIL_BUDGET + 64 <= 156 * 1024;
+    return M >= 1 && M <= 4 && dq::operand_bytes(M, K) + stream_tail_budget(w4) + 64 <= 156 * 1024;
 }
 hipError_t launch_down_activate_stream(const void *GU, const uint8_t *const W[3], const uint8_t *const SFW[3], int M, int N, const int K[3],
                                        bool w4, int round_per_segment, const void *bias, void *D, hipStream_t stream) {

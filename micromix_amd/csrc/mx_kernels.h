@@ -145,7 +145,7 @@ hipError_t launch_rmsnorm_quantize(const void *src, const void *weight, float ep
 // RMSNorm in front of the quantization of the decode launches (mm_rmsnorm_qlinear_decode): weight == nullptr means no norm
 struct NormArgs { const void *weight; float eps; int int_round; };
 constexpr NormArgs NO_NORM = {nullptr, 0.0f, 1};
-int qlinear_decode_supported(int M, int N, const int K[3], bool rms = false);
+int qlinear_decode_supported(int M, int N, const int K[3], bool rms = false, bool w4 = false);
 hipError_t launch_qlinear_decode(const void *X, const int16_t *idx, const uint8_t *const W[3], const uint8_t *const SFW[3],
                                  int M, int N, const int K[3], bool w4, int round_per_segment, const void *bias, void *D,
                                  hipStream_t stream, const NormArgs &norm = NO_NORM);
@@ -161,11 +161,11 @@ hipError_t launch_mx_gemm_stream(const GemmArgs &a, bool w4, hipStream_t stream)
 bool mx_gemm_stream_grouped_supported(int max_m, int ngroups, int N, const int K[3]);
 hipError_t launch_mx_gemm_stream_grouped(const GroupedGemmArgs &ga, int max_m, bool w4, hipStream_t stream);
 // ... with silu(gate) * up + its quantization inside every workgroup (mm_down_activate_decode)
-bool down_activate_stream_supported(int M, int N, const int K[3]);
+bool down_activate_stream_supported(int M, int N, const int K[3], bool w4 = false);   // w4: the ring / reduction tail of fp4 weights is 48 KB, not 64
 hipError_t launch_down_activate_stream(const void *GU, const uint8_t *const W[3], const uint8_t *const SFW[3], int M, int N, const int K[3],
                                        bool w4, int round_per_segment, const void *bias, void *D, hipStream_t stream);
 // ... with the quantization of the M <= 8 activation rows inside every workgroup (mm_qlinear_decode)
-bool qlinear_stream_supported(int M, int N, const int K[3], bool rms = false);
+bool qlinear_stream_supported(int M, int N, const int K[3], bool rms = false, bool w4 = false);
 hipError_t launch_qlinear_stream(const void *X, const int16_t *idx, const uint8_t *const W[3], const uint8_t *const SFW[3], int M, int N,
                                  const int K[3], bool w4, int round_per_segment, const void *bias, void *D, hipStream_t stream,
                                  const NormArgs &norm = NO_NORM);

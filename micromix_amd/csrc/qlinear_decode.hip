@@ -366,7 +366,7 @@ static int decode_features(int N) { return 2 * ((N + 31) / 32) <= device_cus() ?
 // 0: cannot run; 1: can run; 2: can run and is expected to beat quantize + GEMM.  Every workgroup repeats the quantization, in
 // ceil(M * K/32 / 512) passes of ~1.4 us, and the workgroups take ceil(N/features / CUs) rounds; measured on MI355X the fused
 // kernel wins while rounds * passes <= 2 (q/o up to M = 8, gate/up and down up to M = 2-4) and loses beyond.
-int qlinear_decode_supported(int M, int N, const int K[3], bool rms) {
+int qlinear_decode_supported(int M, int N, const int K[3], bool rms, bool w4) {
     const size_t Kt = (size_t)K[0] + K[1] + K[2];
     if (rms && Kt > (size_t)dq::RMS_MAX_K) return 0;
     if (M < 1 || M > 8 || Kt * 2 + decode_operand_bytes(M, K, rms) > DECODE_LDS_MAX) return 0;   // at least one staged row must fit
@@ -377,7 +377,7 @@ int qlinear_decode_supported(int M, int N, const int K[3], bool rms) {
     // the sum of squares too.  Streaming kernel: gate | up N = 28672 (F = 4 on 4 waves) M = 1 18.3 / 17.4 (16.0 once the early-request phase took the norm), M = 4 18.3 / 28.2; N = 14336
     // (F = 2 on 8 waves: 105 + 24 registers, ONE workgroup per CU) M = 1 11.4 / 16.0.  First fused kernel: q | k | v M = 1 11.5 / 9.1,
     // M = 4 11.6 / 11.8; q/o M = 1 9.3 / 7.9, M = 4 9.7 / 10.5.
-    if (qlinear_stream_supported(M, N, K, rms)) {
+    if (qlinear_stream_supported(M, N, K, rms, w4)) {
         if (rms) return (M <= 2 && (N + 31) / 32 > 2 * device_cus() && N <= 32768) ? 2 : 1;      // (M = 2, later in the round: 18.1 / 16.6)
         return (M <= 2 && N <= 32768) ? 2 : 1;
     }
@@ -393,7 +393,7 @@ hipError_t launch_qlinear_decode(const void *X, const int16_t *idx, const uint8_
                                  hipStream_t stream, const NormArgs &norm) {
     using namespace decode;
     const bool rms = norm.weight != nullptr;
-    if (qlinear_stream_supported(M, N, K, rms)) return launch_qlinear_stream(X, idx, W, SFW, M, N, K, w4, round_per_segment, bias, D, stream, norm);
+    if (qlinear_stream_supported(M, N, K, rms, w4)) return launch_qlinear_stream(X, idx, W, SFW, M, N, K, w4, round_per_segment, bias, D, stream, norm);
     Args a;
     a.norm_w = (const uint16_t *)norm.weight;
     a.eps = norm.eps;

@@ -368,6 +368,10 @@ rmsnorm_quantize_ring_kernel(const uint16_t *__restrict__ src, const uint16_t *_
     static_assert(R >= 3 && 5 * (R - 2) < 64, "ring depth");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];   // [R slots][1 KB dump][P floats of partial sums][image of the S | O codes]
     const int T = K >> 5;
+    // The counted wait below, vmcnt(5 (R - 2)), relies on EVERY wave issuing at least one store per row (the scale dword of its lane 0),
+    // i.e. on lane 0 of every wave owning a group: blockDim.x == roundup64(K / 32), as launch_rmsnorm_quantize launches it.  A launch
+    // with surplus waves (DMA pieces but no stores) would let a row be read before it has landed: refuse it loudly.
+    if ((int)blockDim.x != ((T + 63) & ~63)) __builtin_trap();
     const int g = threadIdx.x;
     const bool active = g < T;
     const int wave = __builtin_amdgcn_readfirstlane(g >> 6), lane = g & 63, nw = (int)blockDim.x >> 6;
@@ -511,6 +515,7 @@ hipError_t launch_rmsnorm_quantize(const void *src, const void *weight, float ep
     if (rows == 0) return hipSuccess;
     const int T = K / 32;
     const int groups_per_thread = T > 512 ? 2 : 1;     // K > 16384: rmsnorm_quantize_kernel<*, 2>, 512 threads
+    // (the ring kernel's counted vmcnt needs exactly roundup64(K / 32) threads -- every wave's lane 0 owns a group; it traps otherwise)
     const int threads = ((T + groups_per_thread - 1) / groups_per_thread + 63) / 64 * 64;
     int P = 64;
     while (P < T) P <<= 1;

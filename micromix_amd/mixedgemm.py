@@ -463,10 +463,17 @@ def matmul_grouped(As, Bs, *, biases=None, rounding="reference"):
     return outs
 
 
-def qlinear_decode_supported(M, N, KN, KS, KO):
+def _wmode_of(weight_mode):
+    if weight_mode not in ("w4", "w"):
+        raise ValueError("weight_mode must be 'w4' (fp4 weights, reorder_quantize_w4) or 'w' (matching precision, reorder_quantize_w)")
+    return _lib.MM_W_FP4 if weight_mode == "w4" else _lib.MM_W_MATCH
+
+
+def qlinear_decode_supported(M, N, KN, KS, KO, weight_mode="w4"):
     """0: `qlinear_decode` cannot run this shape (needs 1 <= M <= 8 and the quantized rows in LDS); 1: it can; 2: it can and is
-    expected to be faster than reorder_quantize_x + matmul."""
-    return int(_lib.load().mm_qlinear_decode_supported(int(M), int(N), int(KN), int(KS), int(KO)))
+    expected to be faster than reorder_quantize_x + matmul.  `weight_mode`: the packing of the weights the call will get ("w4": the
+    production mode; its ring in LDS is the smaller one, so longer K fit: mm_qlinear_decode_supported_w)."""
+    return int(_lib.load().mm_qlinear_decode_supported_w(int(M), int(N), int(KN), int(KS), int(KO), _wmode_of(weight_mode)))
 
 
 def gate_up_activate_decode(X, reorder_index, B, DN, DS, DO, *, rounding="reference"):
@@ -515,9 +522,9 @@ def gate_up_activate_decode(X, reorder_index, B, DN, DS, DO, *, rounding="refere
     return oN, oS, oO, sfN, sfS, sfO
 
 
-def down_activate_decode_supported(M, N, DN, DS, DO):
-    """0: cannot run; 1: runs; 2: runs and is expected to beat activate_quantize_x + matmul (mm_down_activate_decode_supported)"""
-    return int(_lib.load().mm_down_activate_decode_supported(int(M), int(N), int(DN), int(DS), int(DO)))
+def down_activate_decode_supported(M, N, DN, DS, DO, weight_mode="w4"):
+    """0: cannot run; 1: runs; 2: runs and is expected to beat activate_quantize_x + matmul (mm_down_activate_decode_supported_w)"""
+    return int(_lib.load().mm_down_activate_decode_supported_w(int(M), int(N), int(DN), int(DS), int(DO), _wmode_of(weight_mode)))
 
 
 def down_activate_decode(GU, B, DN, DS, DO, *, bias=None, rounding="reference"):
@@ -605,9 +612,9 @@ def qlinear_decode(X, reorder_index, BN, BS, BO, SFBN, SFBS, SFBO, KN, KS, KO, *
     return out
 
 
-def rmsnorm_qlinear_decode_supported(M, N, KN, KS, KO):
+def rmsnorm_qlinear_decode_supported(M, N, KN, KS, KO, weight_mode="w4"):
     """0 / 1 / 2 as qlinear_decode_supported, for the launch with the RMSNorm inside (K <= 8192)"""
-    return int(_lib.load().mm_rmsnorm_qlinear_decode_supported(int(M), int(N), int(KN), int(KS), int(KO)))
+    return int(_lib.load().mm_rmsnorm_qlinear_decode_supported_w(int(M), int(N), int(KN), int(KS), int(KO), _wmode_of(weight_mode)))
 
 
 def rmsnorm_qlinear_decode(X, norm_weight, eps, reorder_index, BN, BS, BO, SFBN, SFBS, SFBO, KN, KS, KO, *, bias=None, rounding="reference",

@@ -53,7 +53,13 @@ class _DecodePlan:
     def wins(self, m):
         w = self.benefit.get(m)
         if w is None:
-            w = self.benefit[m] = self.lib.mm_qlinear_decode_supported(m, self.n, *self.split) == 2
+            w = self.benefit[m] = self.lib.mm_qlinear_decode_supported_w(m, self.n, *self.split, self.wmode) == 2
+        return w
+
+    def norm_wins(self, m):
+        w = self.benefit.get(("norm", m))
+        if w is None:
+            w = self.benefit[("norm", m)] = self.lib.mm_rmsnorm_qlinear_decode_supported_w(m, self.n, *self.split, self.wmode) == 2
         return w
 
     def run(self, x2d, bias):
@@ -70,7 +76,8 @@ class _DecodePlan:
         return out
 
 
-    def run_two_op(self, x2d, bias):
+    def run_two_op(self, x2d, bias, norm=None):
+        """quantize (norm = (weight, eps): rmsnorm_quantize_x instead of reorder_quantize_x) + matmul, the split-K scratch from the plan"""
         m = x2d.size(0)
         kn, ks, ko = self.split
         sizes = (m * (kn // 2), m * (ks // 4 * 3), m * ko, mixedgemm._sf_bytes_x(m, kn), mixedgemm._sf_bytes_x(m, ks),
@@ -86,7 +93,7 @@ class _DecodePlan:
             ws_bytes = self.ws_bytes[m] = self.lib.mm_matmul_workspace_bytes(m, self.n, kn, ks, ko, self.wmode, wflags) if m > 32 else 0
         if torch.cuda.current_device() != self.index:
             with torch.cuda.device(self.index):
-                return self.run_two_op(x2d, bias)
+                return self.run_two_op(x2d, bias, norm)
         # one scratch tensor for the quantizer outputs; it is released at return, which is safe because the caching allocator only
         # hands the block to later work on the same stream.  The split-K workspace is the stream's persistent one.
         scratch = torch.empty((total,), dtype=torch.uint8, device=self.device)
@@ -96,7 +103,10 @@ class _DecodePlan:
         out = torch.empty((m, self.n), dtype=torch.bfloat16, device=self.device)
         stream = torch.cuda.current_stream().cuda_stream
         idx, bn, bs, bo, sfbn, sfbs, sfbo = self.args
-        st = self.lib.mm_reorder_quantize(x2d.data_ptr(), m, self.k, idx, kn, ks, ko, 0, *q, stream)
+        if norm is None:
+            st = self.lib.mm_reorder_quantize(x2d.data_ptr(), m, self.k, idx, kn, ks, ko, 0, *q, stream)
+        else:
+            st = self.lib.mm_rmsnorm_quantize(x2d.data_ptr(), norm[0].data_ptr(), float(norm[1]), m, self.k, idx, kn, ks, ko, 0, *q, stream)
         if st == 0:
             st = self.lib.mm_matmul_ws(q[0], bn, q[1], bs, q[2], bo, q[3], sfbn, q[4], sfbs, q[5], sfbo, m, self.n, kn, ks, ko,
                                        self.wmode, wflags, bias.data_ptr() if bias is not None else None, out.data_ptr(),
@@ -116,9 +126,7 @@ def _forward(layer, x):
     else:
         bsz, q_len, k = x.shape
         m = bsz * q_len
-        plan = layer.__dict__.get("_decode_plan")
-        if plan is None or not plan.matches(layer):
-            plan = layer.__dict__["_decode_plan"] = _DecodePlan(layer)
+        plan = _plan_of(layer)
         if x.dtype is not torch.bfloat16 or x.device != plan.device or k != plan.k:
             raise TypeError(f"input must be a bfloat16 tensor [bsz, q_len, {plan.k}] on {plan.device}")
         if bias is not None and bias.device != x.device:
@@ -136,24 +144,43 @@ def _forward(layer, x):
     return y, bsz, q_len
 
 
+def _plan_of(layer):
+    plan = layer.__dict__.get("_decode_plan")
+    if plan is None or not plan.matches(layer):
+        plan = layer.__dict__["_decode_plan"] = _DecodePlan(layer)
+    return plan
+
+
 def _forward_norm(layer, x, norm_weight, eps):
     """RMSNorm(x; norm_weight, eps) -> layer: the reference's caller pattern `layer(rmsnorm_quantize_x(x, w, eps, idx, p4, p6, p8))`
     (model/qLlamaLayer.py: input_layernorm -> q/k/v, post_attention_layernorm -> gate/up; bindings.cpp:257-303).  At decode sizes where
-    it is faster the norm, the quantization and the GEMM are ONE launch (`mixedgemm.rmsnorm_qlinear_decode`); the bytes are the same."""
-    bsz, q_len, k = x.shape
-    m = bsz * q_len
+    it is faster the norm, the quantization and the GEMM are ONE launch (`mixedgemm.rmsnorm_qlinear_decode`); the bytes are the same.
+    x: [bsz, q_len, K], or [tokens, K] (the Mixtral caller's 2-D form: bsz comes back as None).  The same checks, the same empty-batch
+    answer and the same per-layer plan (split-K workspace included) as `_forward`."""
+    if x.dim() == 3:
+        bsz, q_len, k = x.shape
+    elif x.dim() == 2:
+        bsz, (q_len, k) = None, x.shape
+    else:
+        raise TypeError("input must be [bsz, q_len, K] or [tokens, K]")
+    m = q_len if bsz is None else bsz * q_len
+    plan = _plan_of(layer)
+    if x.dtype is not torch.bfloat16 or x.device != plan.device or k != plan.k:
+        raise TypeError(f"input must be a bfloat16 tensor [bsz, q_len, {plan.k}] on {plan.device}")
+    if norm_weight.dtype is not torch.bfloat16 or norm_weight.device != plan.device or norm_weight.numel() != plan.k:
+        raise TypeError(f"norm_weight must be a bfloat16 tensor [{plan.k}] on {plan.device}")
+    if m == 0:
+        return torch.empty((0, plan.n), dtype=torch.bfloat16, device=plan.device), bsz, q_len
     x2d = x.reshape(m, k).contiguous()
-    split = (layer.p4_num, layer.p6_num, layer.p8_num)
+    norm_weight = norm_weight.contiguous()
     bias = layer.bias
     if bias is not None and bias.device != x.device:
         bias = bias.to(x.device)
-    rounding = getattr(layer, "rounding", "reference")
-    if _DECODE_FUSED and 0 < m <= 8 and mixedgemm.rmsnorm_qlinear_decode_supported(m, layer.out_features, *split) == 2:
+    if _DECODE_FUSED and m <= 8 and plan.norm_wins(m):
+        split = plan.split
         return mixedgemm.rmsnorm_qlinear_decode(x2d, norm_weight, eps, layer.reorder_index, layer.BN, layer.BS, layer.BO, layer.SFBN, layer.SFBS,
-                                                layer.SFBO, *split, bias=bias, rounding=rounding), bsz, q_len
-    q = mixedgemm.rmsnorm_quantize_x(x2d, norm_weight, eps, layer.reorder_index, *split)
-    return mixedgemm.matmul(q[0], layer.BN, q[1], layer.BS, q[2], layer.BO, q[3], layer.SFBN, q[4], layer.SFBS, q[5], layer.SFBO,
-                            bias=bias, rounding=rounding), bsz, q_len
+                                                layer.SFBO, *split, bias=bias, rounding=getattr(layer, "rounding", "reference")), bsz, q_len
+    return plan.run_two_op(x2d, bias, norm=(norm_weight, eps)), bsz, q_len
 
 
 def find_qlinear_layers(module, name=""):
@@ -214,7 +241,7 @@ class QLinearLayer(nn.Module):
     def forward_norm(self, x, norm_weight, eps):
         """layer(RMSNorm(x)): x [bsz, q_len, K] bf16 -> [bsz, q_len, N]; see _forward_norm"""
         y, bsz, q_len = _forward_norm(self, x, norm_weight, eps)
-        return y.reshape(bsz, q_len, -1)
+        return y.reshape(bsz, q_len, -1) if bsz is not None else y.reshape(q_len, -1)
 
 
 class FusedQLinear(nn.Module):
@@ -267,6 +294,8 @@ class FusedQLinear(nn.Module):
     def forward_norm(self, x, norm_weight, eps):
         """the fused layers on RMSNorm(x) (input_layernorm -> q | k | v as one launch at decode sizes); see _forward_norm"""
         y, bsz, q_len = _forward_norm(self, x, norm_weight, eps)
+        if bsz is None:
+            return tuple(t.reshape(q_len, -1) for t in y.split(self.splits, dim=1))
         return tuple(t.reshape(bsz, q_len, -1) for t in y.split(self.splits, dim=1))
 
 

@@ -134,7 +134,7 @@ def test_the_stream_guard_detects_planted_violations():
 
 def test_the_build_guards_both_sources(tmp_path):
     from micromix_amd import build
-    assert set(build.GUARDED) == {"mx_gemm256.hip", "mx_gemm_stream.hip", "rmsnorm_quantize.hip", "qlinear_decode.hip"}
+    assert set(build.GUARDED) == {"mx_gemm256.hip", "mx_gemm_tiles_small.hip", "mx_gemm_stream.hip", "rmsnorm_quantize.hip", "qlinear_decode.hip"}
     assert not any("_w1" in s or "persist" in s for s in build.SOURCES)      # round 6: the round-5 experiments are out of the product library
     from micromix_amd import _check_acc_regs as c
     planted = ("_ZN2mm28rmsnorm_quantize_ring_kernelILb1ELi3EEEvPKt: ; @x\n\tglobal_load_dwordx4 v[14:17], v[4:5], off\n"

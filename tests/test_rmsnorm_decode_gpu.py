@@ -110,3 +110,47 @@ def test_layers_forward_norm(dev):
         qh = mixedgemm.activate_quantize_x(gate(tup).reshape(m, inter), up(tup).reshape(m, inter), *mlp.down_split)
         want = mixedgemm.matmul(qh[0], mlp.D_BN, qh[1], mlp.D_BS, qh[2], mlp.D_BO, qh[3], mlp.D_SFBN, qh[4], mlp.D_SFBS, qh[5], mlp.D_SFBO)
         assert torch.equal(mlp(x, nw, 1e-5).reshape(m, k), want)
+
+
+def test_forward_norm_checks_empty_batches_and_2d_input(dev):
+    """forward_norm validates like forward (dtype / device / K), answers an empty batch without a launch, accepts the 2-D
+    token form of the Mixtral caller, and its fallback runs through the layer's plan (mid-M shapes get the split-K workspace)"""
+    import torch
+    from micromix_amd.qlinear import QLinearLayer
+    g = torch.Generator().manual_seed(9)
+    k, p8, p6 = 1024, 384, 128
+    idx = torch.randperm(k, generator=g)
+    layer = QLinearLayer(torch.nn.Linear(k, 256, bias=True, dtype=torch.bfloat16).to(dev), p8, p6, idx)
+    nw = (1.0 + 0.2 * torch.randn((k,), generator=g)).to(torch.bfloat16).to(dev)
+    y = layer.forward_norm(torch.empty((2, 0, k), dtype=torch.bfloat16, device=dev), nw, 1e-5)
+    assert y.shape == (2, 0, 256)
+    with pytest.raises(TypeError):
+        layer.forward_norm(torch.zeros((1, 1, k), dtype=torch.float32, device=dev), nw, 1e-5)
+    with pytest.raises(TypeError):
+        layer.forward_norm(torch.zeros((1, 1, k - 128), dtype=torch.bfloat16, device=dev), nw, 1e-5)
+    with pytest.raises(TypeError):
+        layer.forward_norm(torch.zeros((1, 1, k), dtype=torch.bfloat16, device=dev), nw[:-1], 1e-5)
+    for m in (1, 5, 200):                      # 200 rows of a 256-feature layer: the plan's split-K path
+        x = torch.randn((m, k), generator=g).to(torch.bfloat16).to(dev)
+        y2 = layer.forward_norm(x, nw, 1e-5)                                # [tokens, K] -> [tokens, N]
+        y3 = layer.forward_norm(x.reshape(1, m, k), nw, 1e-5)
+        tup = (*mixedgemm.rmsnorm_quantize_x(x, nw, 1e-5, layer.reorder_index, layer.p4_num, layer.p6_num, layer.p8_num), 1, m)
+        assert y2.shape == (m, 256) and torch.equal(y2, y3.reshape(m, 256)) and torch.equal(y3, layer(tup))
+
+
+def test_supported_queries_take_the_weight_mode():
+    """the ring / reduction tail of fp4 weights is 48 KB, of matching-precision weights 64 KB.  The _w queries budget the mode
+    the launch will run in; the five-argument forms stay conservative (what they accept launches in either mode)."""
+    from micromix_amd import _lib
+    lib = _lib.load()
+    for name in ("mm_qlinear_decode_supported", "mm_rmsnorm_qlinear_decode_supported", "mm_down_activate_decode_supported"):
+        old, new = getattr(lib, name), getattr(lib, name + "_w")
+        for m in (1, 2, 4, 8):
+            for n, split in ((14336, (2048, 128, 1920)), (28672, (3072, 896, 128)), (4096, (12288, 1024, 1024)), (14336, (14336, 1024, 1024)),
+                             (14336, (28672, 2048, 2048))):
+                c, w, f = old(m, n, *split), new(m, n, *split, _lib.MM_W_MATCH), new(m, n, *split, _lib.MM_W_FP4)
+                assert c == w                          # the old form IS the matching-precision answer for a three-segment split
+                assert (f != 0) >= (w != 0)            # fp4 weights never fit less
+        assert new(1, 4096, 4096, 0, 0, 7) == 0       # not a weight mode
+    # a long-K shape only the fp4 budget accepts (K = 16384 at M = 4: ADVICE's example)
+    assert lib.mm_down_activate_decode_supported_w(4, 4096, 14336, 1024, 1024, _lib.MM_W_FP4) != 0
