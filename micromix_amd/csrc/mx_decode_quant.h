@@ -343,5 +343,55 @@ __device__ __forceinline__ LdsMap activate_rows_to_lds(const QuantIn &a, uint8_t
     return m;
 }
 
+// The same with the gate | up values loaded through inline asm IN FRONT of the caller's own untracked loads (`request()`: the first slabs
+// of the weight ring, AFTER_LOADS vector-memory instructions when it returns true) and ONE counted wait -- as quantize_rows_early: the
+// weights are requested ~1 us earlier than from the hook above, which has to wait for the values first (round 6).
+// Precondition (QuantIn::early with mode 1, set by the launcher): ONE pass, M * K / 32 <= NT.
+template <int NT, int AFTER_LOADS, class Request>
+__device__ __forceinline__ LdsMap activate_rows_early(const QuantIn &a, uint8_t *smem, Request request) {
+    const int Kt = a.K[0] + a.K[1] + a.K[2], Gt = Kt >> 5;
+    const int gN = a.K[0] >> 5, gS = a.K[1] >> 5;
+    const int pN = a.K[0] >> 1, pS = (a.K[1] >> 2) * 3, pO = a.K[2];
+    uint8_t *opN = smem, *opS = opN + a.M * pN, *opO = opS + a.M * pS;
+    uint8_t *scales = opO + a.M * pO;
+    const int groups = a.M * Gt, t = threadIdx.x;
+    const bool live = t < groups;
+    const int r = live ? t / Gt : 0, g = live ? t - r * Gt : 0;
+    const uint4 *pa = reinterpret_cast<const uint4 *>(a.X + (size_t)r * (size_t)(2 * Kt) + (size_t)(g >> 2) * 256u + (size_t)(g & 3) * 32u);
+    dq_v4u qa[4], qb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        qa[i] = gload16(pa + i);
+        qb[i] = gload16(pa + 16 + i);
+    }
+    const bool requested = request();
+    if (requested) { MM_DQ_DEVICE_ONLY(asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AFTER_LOADS) : "memory");) }
+    else { MM_DQ_DEVICE_ONLY(asm volatile("s_waitcnt vmcnt(0)" ::: "memory");) }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { MM_DQ_DEVICE_ONLY(asm volatile("" : "+v"(qa[i]), "+v"(qb[i]));) }
+    if (live) {
+        float v[32];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) unpack8(make_uint4(qa[i][0], qa[i][1], qa[i][2], qa[i][3]), v + 8 * i);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float b[8];
+            unpack8(make_uint4(qb[i][0], qb[i][1], qb[i][2], qb[i][3]), b);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[8 * i + e] = silu_mul(v[8 * i + e], b[e]);
+        }
+        uint32_t byte;
+        if (g < gN) byte = quantize32<EL_FP4, false>(v, opN + r * pN + g * 16);
+        else if (g < gN + gS) byte = quantize32<EL_FP6, false>(v, opS + r * pS + (g - gN) * 24);
+        else byte = quantize32<EL_FP8, false>(v, opO + r * pO + (g - gN - gS) * 32);
+        scales[r * Gt + g] = (uint8_t)byte;
+    }
+    __syncthreads();
+    LdsMap m;
+    m.opN = opN; m.opS = opS; m.opO = opO; m.scales = scales;
+    m.pN = pN; m.pS = pS; m.pO = pO; m.Gt = Gt; m.gN = gN; m.gS = gS;
+    return m;
+}
+
 }  // namespace dq
 }  // namespace mm

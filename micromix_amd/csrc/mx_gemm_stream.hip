@@ -373,7 +373,8 @@ __device__ __forceinline__ void stream_body(const GemmArgs &a, const dq::QuantIn
         return cnt > 0;
     };
     if constexpr (QUANT) {
-        if (qi.mode == 1) L = dq::activate_rows_to_lds<NT>(qi, smem_all, [&]() { prime(); });
+        if (qi.mode == 1 && qi.early) L = dq::activate_rows_early<NT, D * RG::LOADS>(qi, smem_all, prime);
+        else if (qi.mode == 1) L = dq::activate_rows_to_lds<NT>(qi, smem_all, [&]() { prime(); });
         else if (qi.early) L = dq::quantize_rows_early<NT, D * RG::LOADS, RMS>(qi, smem_all, prime);
         else L = dq::quantize_rows_to_lds<NT, RMS>(qi, smem_all, [&]() { prime(); });
         const int rr = li < a.M ? li : 0;
@@ -590,6 +591,7 @@ static hipError_t launch_quant(const GemmArgs &a, dq::QuantIn qi, hipStream_t st
     if (rows < 1 && qi.mode != 1) return hipErrorInvalidValue;
     qi.stage_rows = (int)rows;
     qi.early = (qi.mode != 1 && rows >= (size_t)a.M && (size_t)a.M * (Kt / 32) <= 64u * NW && (size_t)a.M * (Kt / 8) <= 64u * NW * dq::EARLY_RL) ? 1 : 0;
+    if (qi.mode == 1) qi.early = (size_t)a.M * (Kt / 32) <= 64u * NW ? 1 : 0;      // activate_rows_early: one pass of the workgroup's threads
     static const int early_on = getenv("MICROMIX_DECODE_EARLY") ? atoi(getenv("MICROMIX_DECODE_EARLY")) : 1;   // kernel-developer override
     if (!early_on) qi.early = 0;
     if (qi.norm_w != nullptr && Kt / 8 > 64u * NW * dq::EARLY_WL) qi.early = 0;     // with the norm the early phase loads the weight vector as EARLY_WL chunks per thread

@@ -12,6 +12,12 @@
 #ifndef MM_DECODE_DEPTH
 #define MM_DECODE_DEPTH 4   // weight slabs a wave requests at once (1 = one memory round trip per slab)
 #endif
+#ifndef MM_DECODE_PREFETCH
+#define MM_DECODE_PREFETCH 2   // A/B builds: 2 = first slabs requested from the quantization phase's hook, 1 = the same code path but requested behind the phase, 0 = the round-5 path
+#endif
+#include <type_traits>
+#include <utility>
+
 #include "mx_decode_quant.h"
 #include "mx_kernels.h"
 
@@ -95,9 +101,10 @@ struct Args {
 
 // this wave's slabs of one segment; xl = LDS base of the segment's quantized rows (pitch xp bytes), sl = LDS base of the
 // segment's scale bytes (pitch sp bytes per row, 4 consecutive bytes per slab)
+// r0: the wave's slabs of the first r0 rounds (w, w + 8, ...) have been taken care of (Prefetch)
 template <int XEL, int WEL>
 __device__ __forceinline__ void run_segment(v16f &acc, const uint8_t *xl, int xp, const uint8_t *sl, int sp, const uint8_t *W,
-                                            const uint8_t *SFW, int nslab, int M, int N, int n0, int sfw_tiles) {
+                                            const uint8_t *SFW, int nslab, int M, int N, int n0, int sfw_tiles, int r0 = 0) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int li = lane & 31, kb = lane >> 5;
     const int wrb = nslab * G<WEL>::BYTES;
@@ -114,7 +121,7 @@ __device__ __forceinline__ void run_segment(v16f &acc, const uint8_t *xl, int xp
     // The weights are the only global loads of this loop and depend on nothing: a wave requests DEPTH of its slabs at once
     // (wave-uniform tests for the tail) and then walks them, instead of paying one memory round trip per slab.
     constexpr int DEPTH = MM_DECODE_DEPTH;
-    for (int s0 = wave; s0 < nslab; s0 += DEPTH * NW) {
+    for (int s0 = wave + r0 * NW; s0 < nslab; s0 += DEPTH * NW) {
         v8i wf[DEPTH][2];
         int swr[DEPTH];
 #pragma unroll
@@ -147,6 +154,97 @@ __device__ __forceinline__ void run_segment(v16f &acc, const uint8_t *xl, int xp
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Round 6: the first weight slabs are requested BEFORE the activation rows are quantized (fp4 weights, the production mode).
+// Until then a workgroup first quantized its rows (rows and indices from L2: ~1 us of latency, ~1 us of arithmetic) and only then asked
+// for its weights (another round trip: ~1 us from the Infinity Cache, ~2 us from HBM) -- and q/k/v/o at K = 4096 are ONE round of
+// requests per wave.  Now every wave requests its first slabs (weights + the rows' scale dwords, straight into registers, through inline
+// asm: hipcc's own wait counts never have to cover them) from the quantization phase's hook, i.e. as soon as the rows are staged, and
+// they travel under the phase's arithmetic.
+// NOT earlier: requested in front of the rows (dq::quantize_rows_early, one counted wait) the launch got 1.5-2.4 us SLOWER (q/o at M = 1
+// 5.6 -> 7.1 us, q | k | v with the norm 9.1 -> 11.5): a CU's memory pipe takes the waves' vector-memory instructions in issue order at
+// 30-45 cycles each, so the rows of waves 1-7 queued behind the weight requests of the waves in front of them, and the phase's first
+// barrier waits for every wave's rows (measured, round 6).
+// The association of the sums is unchanged (slab s of a segment belongs to wave s % 8, a wave adds its slabs in order, the eight partial
+// sums meet in wave order): bit-identical to mx_gemm_skinny.hip as before.
+//   Per segment the first PRE_R rounds (slabs w and w + 8 of wave w): at K = 4096 that is every slab of every split; a slab that does
+//   not exist for this wave requests nothing.
+// ---------------------------------------------------------------------------------------------------------
+typedef int rsrc4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ rsrc4_t make_rsrc4(const uint8_t *base, unsigned bytes) {
+    const unsigned long long v = (unsigned long long)base;
+    rsrc4_t r;
+    r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)v);
+    r[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(v >> 32) & 0xFFFFu));
+    r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+    r[3] = 0x00020000;
+    return r;
+}
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MM_QD_DEVICE_ONLY(...) __VA_ARGS__
+#else
+#define MM_QD_DEVICE_ONLY(...)
+#endif
+// (s_nop 4: SALU / readfirstlane results may not be read by a VMEM instruction for five wait states)
+// `d` is read-write ("+v"): the destination IS the register that holds the caller's zero when the request is skipped (a wave-uniform
+// branch around the statement), so no copy of a pending register is ever needed where the two paths meet
+__device__ __forceinline__ void asm_load16(v4i &d, const rsrc4_t &rs, int voff, int soff) {
+    MM_QD_DEVICE_ONLY(asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen" : "+v"(d) : "v"(voff), "s"(rs), "s"(soff) : "memory");)
+}
+__device__ __forceinline__ void asm_load4(int &d, const rsrc4_t &rs, int voff, int soff) {
+    MM_QD_DEVICE_ONLY(asm volatile("s_nop 4\n\tbuffer_load_dword %0, %1, %2, %3 offen" : "+v"(d) : "v"(voff), "s"(rs), "s"(soff) : "memory");)
+}
+constexpr int PRE_R = 2;                // rounds of a segment (slabs w, w + 8 of wave w) that travel under the quantization phase
+template <int FEAT> struct PreSlab;     // the registers one request fills
+template <> struct PreSlab<16> { v4i w[1]; int sw; };     // lane (row l & 15, K block h = l >> 4): 16 bytes of the row + its scale dword
+template <> struct PreSlab<32> { v4i w[2]; int sw; };     // lane (row l & 31, kb = l >> 5): K blocks kb and 2 + kb
+
+// One segment's first PRE_R rounds.  fp4 weights: the weight rows of every segment are 64 bytes per 128-deep slab.  The segment is a
+// compile-time property of the OBJECT (one per segment in the kernels), so that requests and MFMAs are straight-line code per
+// segment -- a first version with run-time (slot -> segment) dispatch was ~1100 instructions of selects and register copies per wave
+// and cost the launch 1.3 us (tools/time_decode_ab.py, round 6).
+template <int FEAT>
+struct SegPrefetch {
+    PreSlab<FEAT> q[PRE_R];
+    __device__ __forceinline__ void request(const uint8_t *W, const uint8_t *SFW, int nslab, int N, int n0, int sfw_tiles) {
+        constexpr int LI = FEAT - 1, SHIFT = FEAT == 16 ? 4 : 5;
+        const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        const int li = lane & LI, hb = lane >> SHIFT;        // K block of the lane inside a 64-deep (FEAT 32) / 128-deep (FEAT 16) step
+#pragma unroll
+        for (int j = 0; j < PRE_R; ++j) {
+            q[j].sw = 0;
+            q[j].w[0] = v4i{0, 0, 0, 0};
+            if constexpr (FEAT == 32) q[j].w[1] = v4i{0, 0, 0, 0};
+        }
+        if (wave >= nslab) return;                            // (wave-uniform: also the segments that do not exist)
+        int wrows = N - n0;
+        wrows = wrows > FEAT ? FEAT : wrows;
+        const int n = n0 + li, wrb = nslab * 64;
+        const rsrc4_t rw = make_rsrc4(W + (size_t)n0 * wrb, (unsigned)wrows * (unsigned)wrb);
+        const rsrc4_t rs = make_rsrc4(SFW, (unsigned)sfw_tiles * (unsigned)nslab * 512u);
+        const int sfw_off = (n >> 7) * nslab * 512 + (n & 31) * 16 + ((n >> 5) & 3) * 4;
+        const int woff = li * wrb + hb * 16;
+#pragma unroll
+        for (int j = 0; j < PRE_R; ++j) {
+            const int sl = wave + NW * j;
+            if (sl < nslab) {
+                asm_load4(q[j].sw, rs, sfw_off, sl * 512);
+                asm_load16(q[j].w[0], rw, woff, sl * 64);
+                if constexpr (FEAT == 32) asm_load16(q[j].w[1], rw, woff + 32, sl * 64);
+            }
+        }
+    }
+    // (after the wave's s_waitcnt vmcnt(0): the registers are the asm statement's own from here on)
+    __device__ __forceinline__ void landed() {
+#pragma unroll
+        for (int j = 0; j < PRE_R; ++j) {
+            MM_QD_DEVICE_ONLY(asm volatile("" : "+v"(q[j].sw), "+v"(q[j].w[0]));)
+            if constexpr (FEAT == 32) { MM_QD_DEVICE_ONLY(asm volatile("" : "+v"(q[j].w[1]));) }
+        }
+    }
+};
+__device__ __forceinline__ void wait_all_loads() { MM_QD_DEVICE_ONLY(asm volatile("s_waitcnt vmcnt(0)" ::: "memory");) }
+
 using dq::LdsMap;
 template <bool RMS>
 __device__ __forceinline__ LdsMap quantize_rows_to_lds(const Args &a, uint8_t *smem) {
@@ -157,12 +255,35 @@ __device__ __forceinline__ LdsMap quantize_rows_to_lds(const Args &a, uint8_t *s
     q.norm_w = a.norm_w; q.eps = a.eps; q.int_round = a.int_round;
     return dq::quantize_rows_to_lds<NT, RMS>(q, smem);
 }
+// ... with `request()` (vector-memory instructions the compiler does not track) called from the phase's hook, once the first batch of
+// rows is staged
+template <bool RMS, class Request>
+__device__ __forceinline__ LdsMap quantize_rows_to_lds(const Args &a, uint8_t *smem, Request request) {
+    dq::QuantIn q;
+    q.X = a.X; q.idx = a.idx; q.M = a.M; q.stage_rows = a.stage_rows;
+    q.K[0] = a.K[0]; q.K[1] = a.K[1]; q.K[2] = a.K[2];
+    q.mode = 0; q.early = 0;
+    q.norm_w = a.norm_w; q.eps = a.eps; q.int_round = a.int_round;
+    return dq::quantize_rows_to_lds<NT, RMS>(q, smem, [&]() { request(); });
+}
 
 template <bool W4, bool RMS = false>
 __global__ void __launch_bounds__(NT) qlinear_decode_kernel(Args a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];   // [row stage | opN | opS | opO | scales]
     __shared__ float red[NW][16][64];
-    const LdsMap L = quantize_rows_to_lds<RMS>(a, smem);
+    // fp4 weights: the first slabs of the workgroup's first feature block are requested in front of the quantization (Prefetch)
+    [[maybe_unused]] SegPrefetch<32> pfN, pfS, pfO;
+    LdsMap L;
+    constexpr bool PF = W4 && MM_DECODE_PREFETCH != 0;
+    auto request = [&]() {
+        const int n0 = (int)blockIdx.x * BN;
+        pfN.request(a.W[0], a.SFW[0], a.K[0] >> 7, a.N, n0, a.sfw_row_tiles);
+        pfS.request(a.W[1], a.SFW[1], a.K[1] >> 7, a.N, n0, a.sfw_row_tiles);
+        pfO.request(a.W[2], a.SFW[2], a.K[2] >> 7, a.N, n0, a.sfw_row_tiles);
+    };
+    if constexpr (PF && MM_DECODE_PREFETCH == 2) L = quantize_rows_to_lds<RMS>(a, smem, request);
+    else L = quantize_rows_to_lds<RMS>(a, smem);
+    if constexpr (PF && MM_DECODE_PREFETCH == 1) request();
     const uint8_t *opN = L.opN, *opS = L.opS, *opO = L.opO, *scales = L.scales;
     const int pN = L.pN, pS = L.pS, pO = L.pO, Gt = L.Gt, gN = L.gN, gS = L.gS;
 
@@ -176,9 +297,47 @@ __global__ void __launch_bounds__(NT) qlinear_decode_kernel(Args a) {
         v16f accN, accS, accO;
 #pragma unroll
         for (int i = 0; i < 16; ++i) accN[i] = accS[i] = accO[i] = 0.0f;
-        if (nseg[0]) run_segment<EL_FP4, EL_FP4>(accN, opN, pN, scales, Gt, a.W[0], a.SFW[0], nseg[0], a.M, a.N, n0, a.sfw_row_tiles);
-        if (nseg[1]) run_segment<EL_FP6, (W4 ? EL_FP4 : EL_FP6)>(accS, opS, pS, scales + gN, Gt, a.W[1], a.SFW[1], nseg[1], a.M, a.N, n0, a.sfw_row_tiles);
-        if (nseg[2]) run_segment<EL_FP8, (W4 ? EL_FP4 : EL_FP8)>(accO, opO, pO, scales + gN + gS, Gt, a.W[2], a.SFW[2], nseg[2], a.M, a.N, n0, a.sfw_row_tiles);
+        int r0 = 0;
+        if constexpr (PF) {
+            if (n0 == (int)blockIdx.x * BN) {        // the block whose first slabs were requested under the quantization
+                wait_all_loads();
+                pfN.landed(); pfS.landed(); pfO.landed();
+                const int wv = __builtin_amdgcn_readfirstlane(wave), li = lane & 31, kb = lane >> 5, sh = 8 * kb;
+                const bool valid = li < a.M;
+                const int rr = valid ? li : 0;
+                // (the arithmetic of run_segment, slab by slab in the same order)
+                auto steps = [&](auto EL_, v16f &acc, const SegPrefetch<32> &pf, const uint8_t *xl, int xp, const uint8_t *sl, int nslab) {
+                    constexpr int XEL = decltype(EL_)::value;
+#pragma unroll
+                    for (int j = 0; j < PRE_R; ++j) {
+                        const int s = wv + NW * j;
+                        if (s < nslab) {
+                            v8i xf[2];
+                            const v8i zero = {0, 0, 0, 0, 0, 0, 0, 0};
+                            xf[0] = xf[1] = zero;
+                            int sx = 0;
+                            if (valid) {
+                                sx = (int)(*reinterpret_cast<const uint32_t *>(sl + rr * Gt + 4 * s) >> sh);
+#pragma unroll
+                                for (int h = 0; h < 2; ++h) xf[h] = lds_xfrag<XEL>(xl + rr * xp + s * G<XEL>::BYTES, h, kb);
+                            }
+                            const int sw = pf.q[j].sw >> sh;
+                            const v4i a0 = pf.q[j].w[0], a1 = pf.q[j].w[1];
+                            const v8i w0 = {a0[0], a0[1], a0[2], a0[3], 0, 0, 0, 0}, w1 = {a1[0], a1[1], a1[2], a1[3], 0, 0, 0, 0};
+                            acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(xf[0], w0, acc, ElemTraits<XEL>::HW, ElemTraits<EL_FP4>::HW, 0, sx, 0, sw);
+                            acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(xf[1], w1, acc, ElemTraits<XEL>::HW, ElemTraits<EL_FP4>::HW, 2, sx, 2, sw);
+                        }
+                    }
+                };
+                steps(std::integral_constant<int, EL_FP4>{}, accN, pfN, opN, pN, scales, nseg[0]);
+                steps(std::integral_constant<int, EL_FP6>{}, accS, pfS, opS, pS, scales + gN, nseg[1]);
+                steps(std::integral_constant<int, EL_FP8>{}, accO, pfO, opO, pO, scales + gN + gS, nseg[2]);
+                r0 = PRE_R;
+            }
+        }
+        if (nseg[0]) run_segment<EL_FP4, EL_FP4>(accN, opN, pN, scales, Gt, a.W[0], a.SFW[0], nseg[0], a.M, a.N, n0, a.sfw_row_tiles, r0);
+        if (nseg[1]) run_segment<EL_FP6, (W4 ? EL_FP4 : EL_FP6)>(accS, opS, pS, scales + gN, Gt, a.W[1], a.SFW[1], nseg[1], a.M, a.N, n0, a.sfw_row_tiles, r0);
+        if (nseg[2]) run_segment<EL_FP8, (W4 ? EL_FP4 : EL_FP8)>(accO, opO, pO, scales + gN + gS, Gt, a.W[2], a.SFW[2], nseg[2], a.M, a.N, n0, a.sfw_row_tiles, r0);
 
         // cross-wave reduction per segment with the reference's rounding chain (as mx_gemm_skinny.hip)
         float run[2] = {0.0f, 0.0f};
@@ -266,7 +425,7 @@ __device__ __forceinline__ v8i lds_xfrag16(const uint8_t *p, int h) {
 
 template <int XEL, int WEL>
 __device__ __forceinline__ void run_segment16(v4f &acc, const uint8_t *xl, int xp, const uint8_t *sl, int sp, const uint8_t *W,
-                                              const uint8_t *SFW, int nslab, int M, int N, int n0, int sfw_tiles) {
+                                              const uint8_t *SFW, int nslab, int M, int N, int n0, int sfw_tiles, int r0 = 0) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int li = lane & 15, h = lane >> 4;
     const int wrb = nslab * G<WEL>::BYTES;
@@ -281,7 +440,7 @@ __device__ __forceinline__ void run_segment16(v4f &acc, const uint8_t *xl, int x
     const uint8_t *srow = sl + (valid ? li : 0) * sp;
     const int sh = 8 * h;
     constexpr int DEPTH = MM_DECODE_DEPTH;   // as run_segment
-    for (int s0 = wave; s0 < nslab; s0 += DEPTH * NW) {
+    for (int s0 = wave + r0 * NW; s0 < nslab; s0 += DEPTH * NW) {
         v8i wf[DEPTH];
         int swr[DEPTH];
 #pragma unroll
@@ -312,34 +471,80 @@ __device__ __forceinline__ void run_segment16(v4f &acc, const uint8_t *xl, int x
 template <bool W4, bool RMS = false>
 __global__ void __launch_bounds__(NT) qlinear_decode16_kernel(Args a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    __shared__ float red[NW][4][64];
-    const LdsMap L = quantize_rows_to_lds<RMS>(a, smem);
+    __shared__ float red[3][NW][4][64];        // the waves' partial sums of N, S, O side by side: ONE barrier (round 6; was two per segment)
     const int n0 = blockIdx.x * BN16;
+    // fp4 weights: the first slabs are requested in front of the quantization (Prefetch)
+    [[maybe_unused]] SegPrefetch<16> pfN, pfS, pfO;
+    LdsMap L;
+    constexpr bool PF = W4 && MM_DECODE_PREFETCH != 0;
+    auto request = [&]() {
+        pfN.request(a.W[0], a.SFW[0], a.K[0] >> 7, a.N, n0, a.sfw_row_tiles);
+        pfS.request(a.W[1], a.SFW[1], a.K[1] >> 7, a.N, n0, a.sfw_row_tiles);
+        pfO.request(a.W[2], a.SFW[2], a.K[2] >> 7, a.N, n0, a.sfw_row_tiles);
+    };
+    if constexpr (PF && MM_DECODE_PREFETCH == 2) L = quantize_rows_to_lds<RMS>(a, smem, request);
+    else L = quantize_rows_to_lds<RMS>(a, smem);
+    if constexpr (PF && MM_DECODE_PREFETCH == 1) request();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nseg[3] = {a.K[0] >> 7, a.K[1] >> 7, a.K[2] >> 7};
     v4f accN = {0, 0, 0, 0}, accS = {0, 0, 0, 0}, accO = {0, 0, 0, 0};
-    if (nseg[0]) run_segment16<EL_FP4, EL_FP4>(accN, L.opN, L.pN, L.scales, L.Gt, a.W[0], a.SFW[0], nseg[0], a.M, a.N, n0, a.sfw_row_tiles);
-    if (nseg[1]) run_segment16<EL_FP6, (W4 ? EL_FP4 : EL_FP6)>(accS, L.opS, L.pS, L.scales + L.gN, L.Gt, a.W[1], a.SFW[1], nseg[1], a.M, a.N, n0, a.sfw_row_tiles);
-    if (nseg[2]) run_segment16<EL_FP8, (W4 ? EL_FP4 : EL_FP8)>(accO, L.opO, L.pO, L.scales + L.gN + L.gS, L.Gt, a.W[2], a.SFW[2], nseg[2], a.M, a.N, n0, a.sfw_row_tiles);
+    int r0 = 0;
+    if constexpr (PF) {
+        wait_all_loads();
+        pfN.landed(); pfS.landed(); pfO.landed();
+        const int wv = __builtin_amdgcn_readfirstlane(wave), li = lane & 15, h = lane >> 4, sh = 8 * h;
+        const bool valid = li < a.M;
+        const int rr = valid ? li : 0;
+        // (the arithmetic of run_segment16, slab by slab in the same order)
+        auto steps = [&](auto EL_, v4f &acc, const SegPrefetch<16> &pf, const uint8_t *xl, int xp, const uint8_t *sl, int nslab) {
+            constexpr int XEL = decltype(EL_)::value;
+#pragma unroll
+            for (int j = 0; j < PRE_R; ++j) {
+                const int s = wv + NW * j;
+                if (s < nslab) {
+                    int sx = 0;
+                    v8i xf = {0, 0, 0, 0, 0, 0, 0, 0};
+                    if (valid) {
+                        sx = (int)(*reinterpret_cast<const uint32_t *>(sl + rr * L.Gt + 4 * s) >> sh);
+                        xf = lds_xfrag16<XEL>(xl + rr * xp + s * G<XEL>::BYTES, h);
+                    }
+                    const v4i a0 = pf.q[j].w[0];
+                    const v8i w0 = {a0[0], a0[1], a0[2], a0[3], 0, 0, 0, 0};
+                    acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(xf, w0, acc, ElemTraits<XEL>::HW, ElemTraits<EL_FP4>::HW, 0, sx, 0, pf.q[j].sw >> sh);
+                }
+            }
+        };
+        steps(std::integral_constant<int, EL_FP4>{}, accN, pfN, L.opN, L.pN, L.scales, nseg[0]);
+        steps(std::integral_constant<int, EL_FP6>{}, accS, pfS, L.opS, L.pS, L.scales + L.gN, nseg[1]);
+        steps(std::integral_constant<int, EL_FP8>{}, accO, pfO, L.opO, L.pO, L.scales + L.gN + L.gS, nseg[2]);
+        r0 = PRE_R;
+    }
+    if (nseg[0]) run_segment16<EL_FP4, EL_FP4>(accN, L.opN, L.pN, L.scales, L.Gt, a.W[0], a.SFW[0], nseg[0], a.M, a.N, n0, a.sfw_row_tiles, r0);
+    if (nseg[1]) run_segment16<EL_FP6, (W4 ? EL_FP4 : EL_FP6)>(accS, L.opS, L.pS, L.scales + L.gN, L.Gt, a.W[1], a.SFW[1], nseg[1], a.M, a.N, n0, a.sfw_row_tiles, r0);
+    if (nseg[2]) run_segment16<EL_FP8, (W4 ? EL_FP4 : EL_FP8)>(accO, L.opO, L.pO, L.scales + L.gN + L.gS, L.Gt, a.W[2], a.SFW[2], nseg[2], a.M, a.N, n0, a.sfw_row_tiles, r0);
 
-    // cross-wave reduction per segment with the reference's rounding chain; threads 0..255 own one output element each
+    // cross-wave reduction with the reference's rounding chain, segment by segment in the order N, S, O (the same sums in the same order as
+    // mx_gemm_skinny.hip); threads 0..255 own one output element each.  Every wave leaves the partial sums of all present segments first.
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (nseg[0]) red[0][wave][i][lane] = accN[i];
+        if (nseg[1]) red[1][wave][i][lane] = accS[i];
+        if (nseg[2]) red[2][wave][i][lane] = accO[i];
+    }
+    __syncthreads();
     float run = 0.0f;
-    auto reduce = [&](const v4f &acc) {
-        __syncthreads();
+    if (threadIdx.x < 256) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) red[wave][i][lane] = acc[i];
-        __syncthreads();
-        if (threadIdx.x < 256) {
-            float s = 0.0f;
+        for (int g = 0; g < 3; ++g) {
+            if (nseg[g]) {
+                float s = 0.0f;
 #pragma unroll
-            for (int w = 0; w < NW; ++w) s += (&red[w][0][0])[threadIdx.x];
-            s += run;
-            run = a.round_per_segment ? bf16_bits_to_f32(f32_to_bf16_bits(s)) : s;
+                for (int w = 0; w < NW; ++w) s += (&red[g][w][0][0])[threadIdx.x];
+                s += run;
+                run = a.round_per_segment ? bf16_bits_to_f32(f32_to_bf16_bits(s)) : s;
+            }
         }
-    };
-    if (nseg[0]) reduce(accN);
-    if (nseg[1]) reduce(accS);
-    if (nseg[2]) reduce(accO);
+    }
     if (threadIdx.x < 256) {
         const int l = threadIdx.x & 63, i = threadIdx.x >> 6;
         const int m = 4 * (l >> 4) + i;            // D[4 * (lane >> 4) + register][lane & 15]

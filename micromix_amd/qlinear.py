@@ -235,13 +235,13 @@ class QLinearLayer(nn.Module):
     def forward(self, x):
         y, bsz, q_len = _forward(self, x)
         # the Mixtral expert caller passes bsz = None with 2-D token batches (qMixtralLayer.py:507-519)
-        return y.reshape(bsz, q_len, -1) if bsz is not None else y.reshape(q_len, -1)
+        return y.reshape(bsz, q_len, y.size(-1)) if bsz is not None else y.reshape(q_len, y.size(-1))
 
     @torch.no_grad()
     def forward_norm(self, x, norm_weight, eps):
         """layer(RMSNorm(x)): x [bsz, q_len, K] bf16 -> [bsz, q_len, N]; see _forward_norm"""
         y, bsz, q_len = _forward_norm(self, x, norm_weight, eps)
-        return y.reshape(bsz, q_len, -1) if bsz is not None else y.reshape(q_len, -1)
+        return y.reshape(bsz, q_len, y.size(-1)) if bsz is not None else y.reshape(q_len, y.size(-1))
 
 
 class FusedQLinear(nn.Module):
@@ -287,16 +287,16 @@ class FusedQLinear(nn.Module):
     def forward(self, x):
         y, bsz, q_len = _forward(self, x)
         if bsz is None:
-            return tuple(t.reshape(q_len, -1) for t in y.split(self.splits, dim=1))
-        return tuple(t.reshape(bsz, q_len, -1) for t in y.split(self.splits, dim=1))
+            return tuple(t.reshape(q_len, t.size(-1)) for t in y.split(self.splits, dim=1))
+        return tuple(t.reshape(bsz, q_len, t.size(-1)) for t in y.split(self.splits, dim=1))
 
     @torch.no_grad()
     def forward_norm(self, x, norm_weight, eps):
         """the fused layers on RMSNorm(x) (input_layernorm -> q | k | v as one launch at decode sizes); see _forward_norm"""
         y, bsz, q_len = _forward_norm(self, x, norm_weight, eps)
         if bsz is None:
-            return tuple(t.reshape(q_len, -1) for t in y.split(self.splits, dim=1))
-        return tuple(t.reshape(bsz, q_len, -1) for t in y.split(self.splits, dim=1))
+            return tuple(t.reshape(q_len, t.size(-1)) for t in y.split(self.splits, dim=1))
+        return tuple(t.reshape(bsz, q_len, t.size(-1)) for t in y.split(self.splits, dim=1))
 
 
 class FusedMLP(nn.Module):

@@ -201,3 +201,39 @@ def test_the_scratch_guard_covers_every_kernel_and_detects_planted_violations(tm
     assert build.verify_no_scratch(str(tmp_path), "reorder_quantize.hip") == 2
     with pytest.raises(RuntimeError, match="no device assembly"):
         build.verify_no_scratch(str(tmp_path), "capi.hip")
+
+
+W_MODE_PROBE = """
+#include "mx_gemm_prelude.h"
+namespace mm {
+#define MM_NS g256
+#define MM_MAX_STAGES 3
+#define MM_LDS_BUDGET (160 * 1024)
+#define MM_WM 4
+#define MM_TM 2
+#define MM_TN 4
+#define MM_ACC MM_ACC_CLOBBER
+#include "mx_gemm_tile.inc"
+template __global__ void g256::mx_gemm256_kernel<false, false>(GemmArgs);
+}
+"""
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc")
+def test_w_mode_256_row_kernel_keeps_a_register_margin(tmp_path):
+    """The matching-precision 256 x 256 kernel (fp8 weights: two fragment sets of 8-register fragments) is the kernel closest to its
+    register budget: 128 VGPRs beside the 128 accumulators.  Round 5 shipped it one register over (a spill whose reload drained the DMA ring
+    every slab).  Besides the scratch guard of every build, this compiles that ONE kernel with four extra values kept alive across its K
+    loops (-DMM_PRESSURE=4, mx_gemm_tile.inc): still no scratch, i.e. the product kernel has at least four registers to spare."""
+    from micromix_amd import _check_acc_regs as c
+    src = tmp_path / "w_mode_probe.hip"
+    src.write_text(W_MODE_PROBE)
+    out = tmp_path / "k.s"
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-fno-gpu-rdc", "-S", "--cuda-device-only",
+                    "-DMM_PRESSURE=4", "-I", os.path.join(ROOT, "micromix_amd", "csrc"), str(src), "-o", str(out)],
+                   check=True, cwd=str(tmp_path), stderr=subprocess.DEVNULL)
+    text = out.read_text()
+    bad, examined = c.check_scratch(text)
+    assert any("mx_gemm256_kernelILb0ELb0E" in s for s in examined), examined
+    assert not bad, bad
+    assert not c.check(text)          # and the accumulator AGPRs are still the asm's own
