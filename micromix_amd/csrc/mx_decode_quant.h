@@ -211,10 +211,16 @@ __device__ __forceinline__ LdsMap quantize_rows_early(const QuantIn &a, uint8_t 
     dq_v4u iq[4], rq[EARLY_RL], wq[EARLY_WL] = {};
 #pragma unroll
     for (int i = 0; i < 4; ++i) iq[i] = gload16(ip + i);
+    // Which chunks of the rows a thread loads.  Without the norm: chunk t + k NT (side by side).  With it (round 6): group thread (rr, g)
+    // loads ITS OWN four chunks of the reference's summation order, i Gt + g of row rr (rmsnorm.cu:143-160) -- every chunk exactly once,
+    // M Gt <= NT group threads x 4 -- so that its partial sum of squares comes straight from these registers: no second pass over the
+    // staged row, one barrier fewer (tools/stream_clock.py: the phase with the norm was 5.8 us of a 17 us launch).
+    static_assert(!RMS || EARLY_RL == 4, "a group thread's four chunks");
+    auto row_chunk = [&](int k) { return rms ? (t < groups ? rr * (Kt >> 3) + k * Gt + g : -1) : (t + k * NT < chunks ? t + k * NT : -1); };
 #pragma unroll
     for (int k = 0; k < EARLY_RL; ++k) {
-        const int c = t + k * NT;
-        rq[k] = gload16(grow + (c < chunks ? c : chunks - 1));       // (past the end: the last chunk again, not stored)
+        const int c = row_chunk(k);
+        rq[k] = gload16(grow + (c >= 0 ? c : chunks - 1));       // (nothing to load: the last chunk again, not stored)
     }
     if constexpr (rms) {                                                                                   // (see the wait below)
 #pragma unroll
@@ -236,8 +242,8 @@ __device__ __forceinline__ LdsMap quantize_rows_early(const QuantIn &a, uint8_t 
     }
 #pragma unroll
     for (int k = 0; k < EARLY_RL; ++k) {
-        const int c = t + k * NT;
-        if (c < chunks) reinterpret_cast<dq_v4u *>(stage)[c] = rq[k];
+        const int c = row_chunk(k);
+        if (c >= 0) reinterpret_cast<dq_v4u *>(stage)[c] = rq[k];
     }
     if constexpr (rms) {
 #pragma unroll
@@ -245,15 +251,27 @@ __device__ __forceinline__ LdsMap quantize_rows_early(const QuantIn &a, uint8_t 
             const int c = t + k * NT;
             if (c < (Kt >> 3)) reinterpret_cast<dq_v4u *>(wvec)[c] = wq[k];
         }
+        // the reference's partial sums (rms_thread_sum's arithmetic on the group thread's own chunks, i = 0 .. 3, eight elements each, one
+        // after the other) and the zero padding up to P
+        if (t < groups) {
+            float sum = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float x0 = bf16_bits_to_f32(rq[i][k] & 0xFFFFu), x1 = bf16_bits_to_f32(rq[i][k] >> 16);
+                    sum = __builtin_fmaf(x0, x0, sum);
+                    sum = __builtin_fmaf(x1, x1, sum);
+                }
+            part[rr * P + g] = sum;
+        }
+        for (int u = t; u < a.M * (P - Gt); u += NT) {
+            const int r2 = u / (P - Gt);
+            part[r2 * P + Gt + (u - r2 * (P - Gt))] = 0.0f;
+        }
     }
     __syncthreads();
-    if constexpr (rms) {      // as quantize_rows_to_lds: partial sums in the reference's order, the halving tree by one wave per row
-        for (int u = t; u < a.M * P; u += NT) {
-            const int r2 = u / P, t2 = u - r2 * P;
-            const uint4 *row4 = reinterpret_cast<const uint4 *>(stage + (size_t)r2 * Kt * 2);
-            part[u] = t2 < Gt ? rms_thread_sum(t2, Gt, [&](int q) { return row4[q]; }) : 0.0f;
-        }
-        __syncthreads();
+    if constexpr (rms) {      // the halving tree by one wave per row (as quantize_rows_to_lds)
         for (int r2 = t >> 6; r2 < a.M; r2 += NT / 64) {
             const float rv = rms_tree_rvar(part + r2 * P, P, t & 63, Kt, a.eps);
             if ((t & 63) == 0) rvar[r2] = rv;

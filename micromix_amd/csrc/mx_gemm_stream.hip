@@ -476,17 +476,30 @@ __device__ __forceinline__ void stream_body(const GemmArgs &a, const dq::QuantIn
         });
         __syncthreads();
         MM_STAMP(3);
+        // Segment by segment, the thread's PER outputs side by side: the PER * NW reads of a segment are independent and travel together,
+        // then the chain.  (Round 6: with the outputs outside and the segments inside, every segment of every output was its own LDS
+        // round trip -- 12 in a row for 64 features x 3 segments: `reduce+store` 1.9 us of a 14 us launch, tools/stream_clock.py.)
+        // Outputs of token rows past M are neither summed nor stored.
+        bool live[PER];
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
             const int o = threadIdx.x + k * NT;
-            if (o < OUTS) {
-                for (int sl = 0; sl < P; ++sl) {
-                    float s = 0.0f;
+            const int l = o & 63, r = (o >> 6) & 3, t = (o >> 8) % T16;
+            live[k] = o < OUTS && 16 * t + 4 * (l >> 4) + r < a.M;
+        }
+        for (int sl = 0; sl < P; ++sl) {
+            float s[PER];
 #pragma unroll
-                    for (int w = 0; w < NW; ++w) s += red[((size_t)w * P + sl) * IMG + o];
-                    chain(k, s);
+            for (int k = 0; k < PER; ++k) {
+                const int o = threadIdx.x + k * NT;
+                s[k] = 0.0f;
+                if (live[k]) {
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) s[k] += red[((size_t)w * P + sl) * IMG + o];
                 }
             }
+#pragma unroll
+            for (int k = 0; k < PER; ++k) chain(k, s[k]);
         }
     }
     // output o = (i = f * T16 + t, r, l): token 16 t + 4 (l >> 4) + r, feature n0 + 16 f + (l & 15)

@@ -17,7 +17,7 @@ rm -rf $OUT; mkdir -p $OUT
 cd $REPO
 python3 bench.py --steps 20 --warmup 5 > $OUT/bench_plain.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 20 --warmup 5 > $OUT/bench_under_rocprof.log 2>&1
-for cfg in "fp8 0,0,4096" "fp4 4096,0,0" "mixed 2048,128,1920" "mixed3072 3072,896,128" "down 12288,1024,1024@4096x4096x14336" \
+for cfg in "fp8 0,0,4096" "fp8w w:0,0,4096" "fp4 4096,0,0" "mixed 2048,128,1920" "mixed3072 3072,896,128" "down 12288,1024,1024@4096x4096x14336" \
            "few 2048,128,1920@128x4096x4096" "kv 2048,128,1920@128x1024x4096" "decode 2048,128,1920@1x4096x4096" \
            "stream 2048,128,1920@16x14336x4096" "gateup act:2048,128,1920"; do
   set -- $cfg

@@ -42,7 +42,7 @@ if plain:
     lines.append(plain[-1].strip())
 traffic = None
 SMALL = ("few", "kv", "decode", "stream", "gateup")     # launches that are not ONE round of 256 eight-wave workgroups: ratios only
-for name in ("fp8", "fp4", "mixed", "mixed3072", "down") + SMALL:   # (gateup: 1792 workgroups of the fused gate / up kernel)
+for name in ("fp8", "fp8w", "fp4", "mixed", "mixed3072", "down") + SMALL:   # (gateup: 1792 workgroups of the fused gate / up kernel)
     d = os.path.join(root, "gpurun_out", f"pmc_{tag}_{name}")
     agg = collections.defaultdict(list)
     for f in glob.glob(d + "/*/*/*_counter_collection.csv"):
