@@ -190,6 +190,8 @@ __device__ unsigned long long *g_stream_clock;
 // its first batch of rows is staged it requests its first D slabs of weights, and the activation fragments and scales of a slab come
 // from that LDS copy (rows in the reference's packed layout, as in qlinear_decode.hip).  `qbytes` = the quantization's LDS range in
 // front of the rings.
+// slots per thread of dq::quantize_rows_early (see there): 2 on the four-wave kernels, whose register count costs no resident workgroup
+template <int NW> constexpr int EARLY_NPASS = NW <= 4 ? 2 : 1;
 template <int F, int T16, int D, int NW, bool W4, bool QUANT = false, bool RMS = false>
 __device__ __forceinline__ void stream_body(const GemmArgs &a, const dq::QuantIn &qi = dq::QuantIn(), int qbytes = 0) {
     static_assert(T16 <= 4, "64 token rows: row groups 0 and 1 of the activation scale atoms, both in the 8 bytes a lane loads");
@@ -373,10 +375,13 @@ __device__ __forceinline__ void stream_body(const GemmArgs &a, const dq::QuantIn
         return cnt > 0;
     };
     if constexpr (QUANT) {
-        if (qi.mode == 1 && qi.early) L = dq::activate_rows_early<NT, D * RG::LOADS>(qi, smem_all, prime);
-        else if (qi.mode == 1) L = dq::activate_rows_to_lds<NT>(qi, smem_all, [&]() { prime(); });
-        else if (qi.early) L = dq::quantize_rows_early<NT, D * RG::LOADS, RMS>(qi, smem_all, prime);
-        else L = dq::quantize_rows_to_lds<NT, RMS>(qi, smem_all, [&]() { prime(); });
+        // (the activation mode has no norm: its 32 + 32 registers stay out of the norm kernels' allocation)
+        if (!RMS && qi.mode == 1 && qi.early) L = dq::activate_rows_early<NT, D * RG::LOADS>(qi, smem_all, prime);
+        else if (!RMS && qi.mode == 1) L = dq::activate_rows_to_lds<NT>(qi, smem_all, [&]() { prime(); });
+        else if (qi.early) L = dq::quantize_rows_early<NT, D * RG::LOADS, RMS, EARLY_NPASS<NW>>(qi, smem_all, prime);
+        // (whatever fits one pass of lane pairs went the early way: the staged path runs one lane per group -- except in the norm's
+        // eight-wave 32-feature kernel, whose register count decides between one and two workgroups per CU)
+        else L = dq::quantize_rows_to_lds<NT, RMS, (RMS && NW == 8 && F == 2) ? 2 : 1>(qi, smem_all, [&]() { prime(); });
         const int rr = li < a.M ? li : 0;
         qx[0] = L.opN + rr * L.pN + 16 * h;
         qx[1] = L.opS + rr * L.pS + 24 * h;
@@ -603,11 +608,10 @@ static hipError_t launch_quant(const GemmArgs &a, dq::QuantIn qi, hipStream_t st
     }
     if (rows < 1 && qi.mode != 1) return hipErrorInvalidValue;
     qi.stage_rows = (int)rows;
-    qi.early = (qi.mode != 1 && rows >= (size_t)a.M && (size_t)a.M * (Kt / 32) <= 64u * NW && (size_t)a.M * (Kt / 8) <= 64u * NW * dq::EARLY_RL) ? 1 : 0;
+    qi.early = (qi.mode != 1 && rows >= (size_t)a.M && dq::early_fits(a.M, (int)Kt, 64 * NW, EARLY_NPASS<NW>)) ? 1 : 0;
     if (qi.mode == 1) qi.early = (size_t)a.M * (Kt / 32) <= 64u * NW ? 1 : 0;      // activate_rows_early: one pass of the workgroup's threads
     static const int early_on = getenv("MICROMIX_DECODE_EARLY") ? atoi(getenv("MICROMIX_DECODE_EARLY")) : 1;   // kernel-developer override
     if (!early_on) qi.early = 0;
-    if (qi.norm_w != nullptr && Kt / 8 > 64u * NW * dq::EARLY_WL) qi.early = 0;     // with the norm the early phase loads the weight vector as EARLY_WL chunks per thread
     const size_t qbytes = rows * Kt * 2 + ops, lds = qbytes + tail;
     if (lds > LDS_WG) return hipErrorInvalidValue;      // (every mode: the supported() predicates keep callers away from this)
     static DynamicLdsOnce once;

@@ -246,28 +246,31 @@ struct SegPrefetch {
 __device__ __forceinline__ void wait_all_loads() { MM_QD_DEVICE_ONLY(asm volatile("s_waitcnt vmcnt(0)" ::: "memory");) }
 
 using dq::LdsMap;
-template <bool RMS>
+template <bool RMS, int LPG>
 __device__ __forceinline__ LdsMap quantize_rows_to_lds(const Args &a, uint8_t *smem) {
     dq::QuantIn q;
     q.X = a.X; q.idx = a.idx; q.M = a.M; q.stage_rows = a.stage_rows;
     q.K[0] = a.K[0]; q.K[1] = a.K[1]; q.K[2] = a.K[2];
     q.mode = 0; q.early = 0;
     q.norm_w = a.norm_w; q.eps = a.eps; q.int_round = a.int_round;
-    return dq::quantize_rows_to_lds<NT, RMS>(q, smem);
+    return dq::quantize_rows_to_lds<NT, RMS, LPG>(q, smem);
 }
 // ... with `request()` (vector-memory instructions the compiler does not track) called from the phase's hook, once the first batch of
 // rows is staged
-template <bool RMS, class Request>
+template <bool RMS, int LPG, class Request>
 __device__ __forceinline__ LdsMap quantize_rows_to_lds(const Args &a, uint8_t *smem, Request request) {
     dq::QuantIn q;
     q.X = a.X; q.idx = a.idx; q.M = a.M; q.stage_rows = a.stage_rows;
     q.K[0] = a.K[0]; q.K[1] = a.K[1]; q.K[2] = a.K[2];
     q.mode = 0; q.early = 0;
     q.norm_w = a.norm_w; q.eps = a.eps; q.int_round = a.int_round;
-    return dq::quantize_rows_to_lds<NT, RMS>(q, smem, [&]() { request(); });
+    return dq::quantize_rows_to_lds<NT, RMS, LPG>(q, smem, [&]() { request(); });
 }
 
-template <bool W4, bool RMS = false>
+// LPG: lanes per reordered group in the quantization phase (dq::quantize_rows_to_lds): 2 when the launch's (row, group, half) slots fit
+// one pass of the workgroup (M <= 2 at K = 4096), else 1 -- kernels of their own: with both paths in one kernel the one-lane path ran
+// 0.3 - 2 us slower than alone (q | k | v with the norm at M = 8: 16.1 -> 18.1 us)
+template <bool W4, bool RMS = false, int LPG = 1>
 __global__ void __launch_bounds__(NT) qlinear_decode_kernel(Args a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];   // [row stage | opN | opS | opO | scales]
     __shared__ float red[NW][16][64];
@@ -281,8 +284,8 @@ __global__ void __launch_bounds__(NT) qlinear_decode_kernel(Args a) {
         pfS.request(a.W[1], a.SFW[1], a.K[1] >> 7, a.N, n0, a.sfw_row_tiles);
         pfO.request(a.W[2], a.SFW[2], a.K[2] >> 7, a.N, n0, a.sfw_row_tiles);
     };
-    if constexpr (PF && MM_DECODE_PREFETCH == 2) L = quantize_rows_to_lds<RMS>(a, smem, request);
-    else L = quantize_rows_to_lds<RMS>(a, smem);
+    if constexpr (PF && MM_DECODE_PREFETCH == 2) L = quantize_rows_to_lds<RMS, LPG>(a, smem, request);
+    else L = quantize_rows_to_lds<RMS, LPG>(a, smem);
     if constexpr (PF && MM_DECODE_PREFETCH == 1) request();
     const uint8_t *opN = L.opN, *opS = L.opS, *opO = L.opO, *scales = L.scales;
     const int pN = L.pN, pS = L.pS, pO = L.pO, Gt = L.Gt, gN = L.gN, gS = L.gS;
@@ -468,7 +471,7 @@ __device__ __forceinline__ void run_segment16(v4f &acc, const uint8_t *xl, int x
     }
 }
 
-template <bool W4, bool RMS = false>
+template <bool W4, bool RMS = false, int LPG = 1>
 __global__ void __launch_bounds__(NT) qlinear_decode16_kernel(Args a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     __shared__ float red[3][NW][4][64];        // the waves' partial sums of N, S, O side by side: ONE barrier (round 6; was two per segment)
@@ -482,8 +485,8 @@ __global__ void __launch_bounds__(NT) qlinear_decode16_kernel(Args a) {
         pfS.request(a.W[1], a.SFW[1], a.K[1] >> 7, a.N, n0, a.sfw_row_tiles);
         pfO.request(a.W[2], a.SFW[2], a.K[2] >> 7, a.N, n0, a.sfw_row_tiles);
     };
-    if constexpr (PF && MM_DECODE_PREFETCH == 2) L = quantize_rows_to_lds<RMS>(a, smem, request);
-    else L = quantize_rows_to_lds<RMS>(a, smem);
+    if constexpr (PF && MM_DECODE_PREFETCH == 2) L = quantize_rows_to_lds<RMS, LPG>(a, smem, request);
+    else L = quantize_rows_to_lds<RMS, LPG>(a, smem);
     if constexpr (PF && MM_DECODE_PREFETCH == 1) request();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nseg[3] = {a.K[0] >> 7, a.K[1] >> 7, a.K[2] >> 7};
@@ -583,7 +586,12 @@ int qlinear_decode_supported(int M, int N, const int K[3], bool rms, bool w4) {
     // (F = 2 on 8 waves: 105 + 24 registers, ONE workgroup per CU) M = 1 11.4 / 16.0.  First fused kernel: q | k | v M = 1 11.5 / 9.1,
     // M = 4 11.6 / 11.8; q/o M = 1 9.3 / 7.9, M = 4 9.7 / 10.5.
     if (qlinear_stream_supported(M, N, K, rms, w4)) {
-        if (rms) return (M <= 2 && (N + 31) / 32 > 2 * device_cus() && N <= 32768) ? 2 : 1;      // (M = 2, later in the round: 18.1 / 16.6)
+        // (round 6, lane pairs in the quantization phase: the 32-feature norm kernel holds two workgroups per CU -- N = 14336 M = 1 13.3 / 9.5,
+        // M = 2 13.6 / 11.8; gate | up M = 1 17.8 / 15.0, M = 2 17.8 / 16.7.  Only while the slots fit the early-request phase, 2 M K / 32 <= 512:
+        // at K = 8192 M = 2 goes through the staged path, 13.0 -> 13.9)
+        // Beyond K = 4096 the staged row, the operands and the norm's weight vector leave room for ONE workgroup per CU: one round of them
+        // only (Llama-3-70B shapes, K = 8192, M = 1: q/o N = 8192 12.8 / 11.1; q | k | v N = 10240 16.7 / 18.6)
+        if (rms) return (M <= 2 && N <= 32768 && 2 * (size_t)M * (Kt / 32) <= 512 && (Kt <= 4096 || (N + 31) / 32 <= device_cus())) ? 2 : 1;
         return (M <= 2 && N <= 32768) ? 2 : 1;
     }
     const int feat = decode_features(N), cus = device_cus();
@@ -622,12 +630,18 @@ hipError_t launch_qlinear_decode(const void *X, const int16_t *idx, const uint8_
     a.stage_rows = stage_rows;
     const size_t lds = (size_t)stage_rows * Kt * 2 + ops;
     const bool f16 = decode_features(N) == 16;
-    auto kern = rms ? (f16 ? (w4 ? qlinear_decode16_kernel<true, true> : qlinear_decode16_kernel<false, true>)
-                           : (w4 ? qlinear_decode_kernel<true, true> : qlinear_decode_kernel<false, true>))
-                    : (f16 ? (w4 ? qlinear_decode16_kernel<true> : qlinear_decode16_kernel<false>)
-                           : (w4 ? qlinear_decode_kernel<true> : qlinear_decode_kernel<false>));
-    static DynamicLdsOnce done[8];
-    if (hipError_t e = done[(rms ? 4 : 0) + (f16 ? 2 : 0) + (w4 ? 0 : 1)].ensure(reinterpret_cast<const void *>(kern), (int)DECODE_LDS_MAX); e != hipSuccess)
+    // lane pairs in the quantization phase when one pass of the workgroup covers every (row, group, half) slot (see the kernels)
+    const bool pairs = 2 * (size_t)stage_rows * (Kt / 32) <= (size_t)NT;
+    auto pick = [&](auto lpg_) {
+        constexpr int L = decltype(lpg_)::value;
+        return rms ? (f16 ? (w4 ? qlinear_decode16_kernel<true, true, L> : qlinear_decode16_kernel<false, true, L>)
+                          : (w4 ? qlinear_decode_kernel<true, true, L> : qlinear_decode_kernel<false, true, L>))
+                   : (f16 ? (w4 ? qlinear_decode16_kernel<true, false, L> : qlinear_decode16_kernel<false, false, L>)
+                          : (w4 ? qlinear_decode_kernel<true, false, L> : qlinear_decode_kernel<false, false, L>));
+    };
+    auto kern = pairs ? pick(std::integral_constant<int, 2>{}) : pick(std::integral_constant<int, 1>{});
+    static DynamicLdsOnce done[16];
+    if (hipError_t e = done[(pairs ? 8 : 0) + (rms ? 4 : 0) + (f16 ? 2 : 0) + (w4 ? 0 : 1)].ensure(reinterpret_cast<const void *>(kern), (int)DECODE_LDS_MAX); e != hipSuccess)
         return e;
     const int feat = f16 ? BN16 : BN;
     int blocks = (N + feat - 1) / feat;

@@ -18,7 +18,8 @@ def timed(fn, n=300):
     return e0.elapsed_time(e1) / n * 1000
 for name, N, K, split in (("q/o", 4096, 4096, (2048, 128, 1920)), ("qkv fused", 6144, 4096, (2048, 128, 1920)), ("k/v", 1024, 4096, (2048, 128, 1920)),
                           ("gate/up", 14336, 4096, (2048, 128, 1920)), ("gate+up fused", 28672, 4096, (2048, 128, 1920)),
-                          ("down", 4096, 14336, (7168, 512, 6656))):
+                          ("down", 4096, 14336, (7168, 512, 6656))) + ((("70B q/o", 8192, 8192, (4096, 256, 3840)), ("70B qkv", 10240, 8192, (4096, 256, 3840)),
+                          ("70B gate+up", 57344, 8192, (4096, 256, 3840))) if os.environ.get("TD_70B") else ()):
     w = (torch.randn((N, K), generator=g) * 0.02).to(torch.bfloat16).to(dev)
     for M in (1, 2, 4, 8):
         x = torch.randn((M, K), generator=g).to(torch.bfloat16).to(dev)

@@ -1,5 +1,6 @@
 """A/B of the fused decode launch (mm_qlinear_decode / mm_rmsnorm_qlinear_decode) across library variants, one process per variant
-(MICROMIX_HIP_LIB), interleaved passes: python tools/time_decode_ab.py lib_a.so lib_b.so ...  ("default" = the product library)"""
+(MICROMIX_HIP_LIB), interleaved passes: python tools/time_decode_ab.py lib_a.so lib_b.so ...  ("default" = the product library);
+AB_SHAPES=wide: the streaming kernel's layers; AB_PASSES=n"""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CHILD = r'''
@@ -20,9 +21,12 @@ def timed(fn, n=400):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1000
 out = []
-for name, N, K, split in (("q/o", 4096, 4096, (2048, 128, 1920)), ("qkv", 6144, 4096, (2048, 128, 1920)), ("k/v", 1024, 4096, (2048, 128, 1920)), ("q/o fp8", 4096, 4096, (0, 0, 4096))):
+SHAPES = (("q/o", 4096, 4096, (2048, 128, 1920)), ("qkv", 6144, 4096, (2048, 128, 1920)), ("k/v", 1024, 4096, (2048, 128, 1920)), ("q/o fp8", 4096, 4096, (0, 0, 4096)))
+if os.environ.get("AB_SHAPES") == "wide":      # the streaming kernel's layers
+    SHAPES = (("gate/up", 14336, 4096, (2048, 128, 1920)), ("gate+up", 28672, 4096, (2048, 128, 1920)), ("q/o 70B", 8192, 8192, (4096, 256, 3840)))
+for name, N, K, split in SHAPES:
     w = (torch.randn((N, K), generator=g) * 0.02).to(torch.bfloat16).to(dev)
-    for M in (1, 4, 8):
+    for M in (1, 2, 4, 8):
         x = torch.randn((M, K), generator=g).to(torch.bfloat16).to(dev)
         idx = torch.argsort(x.float().abs().mean(0)).to(torch.int16)
         b = mixedgemm.reorder_quantize_w4(w, idx, *split)
@@ -35,7 +39,7 @@ for name, N, K, split in (("q/o", 4096, 4096, (2048, 128, 1920)), ("qkv", 6144, 
 print(" | ".join(out))
 ''' % ROOT
 libs = sys.argv[1:] or ["default"]
-for p in range(2):
+for p in range(int(os.environ.get('AB_PASSES', '2'))):
     for l in libs:
         env = dict(os.environ)
         if l != "default":
