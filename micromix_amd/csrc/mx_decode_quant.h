@@ -585,6 +585,10 @@ __device__ __forceinline__ LdsMap activate_rows_to_lds(const QuantIn &a, uint8_t
 // of the weight ring, AFTER_LOADS vector-memory instructions when it returns true) and ONE counted wait -- as quantize_rows_early: the
 // weights are requested ~1 us earlier than from the hook above, which has to wait for the values first (round 6).
 // Precondition (QuantIn::early with mode 1, set by the launcher): ONE pass, M * K / 32 <= NT.
+// (Round 6, measured and dropped: FOUR lanes per group -- a lane owns one 16-byte chunk of gate and of up, the absmax meets by DPP, every
+// load instruction covers contiguous runs of 256 bytes.  down_proj at M = 1 the same 9.4 us, M = 2 11.0 -> 12.4, M = 4 13.7 -> 17.7: with
+// K = 14336 one lane per group already keeps 448 of 512 threads busy, so a thread's chain of silu does not get shorter, there are only
+// more passes; lane-contiguous loads alone were worth 0.35 us.)
 template <int NT, int AFTER_LOADS, class Request>
 __device__ __forceinline__ LdsMap activate_rows_early(const QuantIn &a, uint8_t *smem, Request request) {
     const int Kt = a.K[0] + a.K[1] + a.K[2], Gt = Kt >> 5;

@@ -162,7 +162,8 @@ __device__ __forceinline__ void static_for(Fn &&fn) {
 }
 
 // one slot of a wave's LDS ring: F weight tiles (one 1 KB piece each with fp4 weights, two otherwise), T16 activation tiles of two pieces
-// (QUANT: the workgroup quantizes the activation rows itself, mx_decode_quant.h -- no activation tiles, no activation scale atom)
+// (QUANT: the workgroup quantizes the activation rows itself, mx_decode_quant.h -- no activation tiles, no activation scale atom, and the
+// weights' scales come from the wave's scale image, see scale_image_bytes: no scale atom per slab either)
 template <int F, int T16, bool W4, bool QUANT = false>
 struct Ring {
     static constexpr int WP = W4 ? 1 : 2;
@@ -170,7 +171,7 @@ struct Ring {
     // vector-memory instructions of a slab, at least: the second piece of an activation tile is requested only where it holds rows the
     // launch has (fp4 tiles are one piece; M <= 8: rows 0 .. 7 sit in the first piece of every format).  The counted waits use this
     // minimum -- with longer slabs behind it a wait lets at most one instruction fewer stay in flight, never one too many.
-    static constexpr int LOADS = ((MM_STREAM_DBG & 16) ? 0 : F * WP) + ((MM_STREAM_DBG & 1) || QUANT ? 0 : T16) + ((MM_STREAM_DBG & 2) ? 0 : (QUANT ? 1 : 2));
+    static constexpr int LOADS = ((MM_STREAM_DBG & 16) ? 0 : F * WP) + ((MM_STREAM_DBG & 1) || QUANT ? 0 : T16) + ((MM_STREAM_DBG & 2) || QUANT ? 0 : 2);
 };
 
 // chunks per row of a segment's 128-deep slab: fp4 4, fp6 6, fp8 8 (x 16 bytes)
@@ -190,6 +191,29 @@ __device__ unsigned long long *g_stream_clock;
 // its first batch of rows is staged it requests its first D slabs of weights, and the activation fragments and scales of a slab come
 // from that LDS copy (rows in the reference's packed layout, as in qlinear_decode.hip).  `qbytes` = the quantization's LDS range in
 // front of the rings.
+// QUANT kernels: the scale image.  A slab's 512-byte scale atom carries the scales of 128 weight rows; a workgroup wants 16 F of them, and
+// a launch of these kernels is the sum of its vector-memory instructions (30-45 cycles each on a CU, whatever they fetch): with one atom
+// load per slab the scales cost as much as the fp4 weights themselves (down_proj at M = 1, tools/stream_clock.py: loop 5.2 us, without the
+// scale loads 2.8; the whole launch 11.0 -> 8.6).  So a wave gathers the scale dwords of ALL of its slabs in front of everything else --
+// one dword per lane = (slab, weight row), 64 / (16 F) slabs per instruction, global -> LDS directly -- into a private image
+// [instruction k][lane] of dwords, and a step reads its scale bytes from there.
+__host__ __device__ constexpr int scale_image_wave_bytes(int F, int NW, int T) {      // T = 128-deep slabs of the launch
+    const int spi = 4 / F, per_wave = (T + NW - 1) / NW;
+    return (per_wave + spi - 1) / spi * 256;
+}
+__host__ __device__ constexpr int scale_image_bytes(int F, int NW, int T) { return NW * scale_image_wave_bytes(F, NW, T); }
+// one global_load_lds_dword: lane l's dword at `p` -> LDS byte lds + 4 l (M0 = lds; counted by vmcnt like the ring's DMA)
+// (M0 is saved and restored by the caller, once around its loop: m0_save / m0_restore)
+__device__ __forceinline__ void dma4(const uint8_t *p, unsigned lds) {
+    MM_DEVICE_ONLY(asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" : : "v"(p), "s"(lds) : "memory");)
+}
+__device__ __forceinline__ unsigned m0_save() {
+    unsigned keep = 0;
+    MM_DEVICE_ONLY(asm volatile("s_mov_b32 %0, m0" : "=s"(keep) : : "memory");)
+    return keep;
+}
+__device__ __forceinline__ void m0_restore(unsigned keep) { MM_DEVICE_ONLY(asm volatile("s_mov_b32 m0, %0" : : "s"(keep) : "memory");) }
+
 // slots per thread of dq::quantize_rows_early (see there): 2 on the four-wave kernels, whose register count costs no resident workgroup
 template <int NW> constexpr int EARLY_NPASS = NW <= 4 ? 2 : 1;
 template <int F, int T16, int D, int NW, bool W4, bool QUANT = false, bool RMS = false>
@@ -197,7 +221,7 @@ __device__ __forceinline__ void stream_body(const GemmArgs &a, const dq::QuantIn
     static_assert(T16 <= 4, "64 token rows: row groups 0 and 1 of the activation scale atoms, both in the 8 bytes a lane loads");
     static_assert(!QUANT || T16 == 1, "M <= 8");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem_all[];  // [QUANT: staged rows | quantized rows | scale bytes] the waves' rings [NW][D][Ring::SLOT]; then the reduction image over the rings
-    uint8_t *const smem = smem_all + qbytes;
+    uint8_t *const smem = smem_all + qbytes;      // (QUANT: the scale image sits behind the rings, under the part of the reduction image they leave free)
     MM_STAMP(0);
     using RG = Ring<F, T16, W4, QUANT>;
     static_assert((D - 1) * RG::LOADS < 64, "vmcnt is a 6-bit counter");
@@ -212,6 +236,37 @@ __device__ __forceinline__ void stream_body(const GemmArgs &a, const dq::QuantIn
                                                         // 8 .. 15 of the LDS image then hold stale bytes; their outputs are never stored)
     const unsigned ring = __builtin_amdgcn_readfirstlane(lds_address(smem) + wave * D * RG::SLOT);   // LDS byte address of slot 0
     const uint8_t *const ringp = smem + wave * D * RG::SLOT;
+
+    // this wave's slabs: j = wave + NW * i, i = 0 .. cnt-1
+    const int cnt = wave < T ? (T - wave + NW - 1) / NW : 0;
+    // QUANT: the wave's scale image (see scale_image_bytes) is requested before anything else, so every later wait covers it
+    [[maybe_unused]] const uint8_t *simg = nullptr;       // + 4 (16 F k' + row) + K block: the scale byte of (slab i = 4 / F k + k', row) -- see consume_g
+    if constexpr (QUANT && !(MM_STREAM_DBG & 2)) {
+        constexpr int R = 16 * F, SPI = 64 / R;
+        const int wimg = scale_image_wave_bytes(F, NW, T);
+        const uint8_t *img = smem + NW * D * RG::SLOT + wave * wimg;
+        const unsigned img_lds = __builtin_amdgcn_readfirstlane(lds_address(img));
+        const int qd = lane / R, n = n0 + (lane % R);
+        const int aoff = (n & 31) * 16 + ((n >> 5) & 3) * 4;      // (atom row n & 31, row group (n >> 5) & 3): the dword of weight row n
+        // (the three pointers as opaque scalars: hipcc otherwise turns the per-lane select between them into a per-lane LOAD from the
+        // kernel-argument segment, with a wait for every outstanding load behind it, in every trip of the loop)
+        const uint8_t *sf0 = a.SFW[0], *sf1 = a.SFW[1], *sf2 = a.SFW[2];
+        MM_DEVICE_ONLY(asm volatile("" : "+s"(sf0), "+s"(sf1), "+s"(sf2));)
+        const uint8_t *const safe = ns[0] ? sf0 : (ns[1] ? sf1 : sf2);
+        const unsigned keep_m0 = m0_save();
+#pragma unroll 1
+        for (int k = 0; k * SPI < cnt; ++k) {
+            const int i = k * SPI + qd, j = wave + NW * i;
+            // (selects, not arrays indexed by the lane's segment: those would live in scratch)
+            const bool g0 = j < c1, g1 = j < c2;
+            const int sl = j - (g0 ? 0 : (g1 ? c1 : c2)), nsg = g0 ? ns[0] : (g1 ? ns[1] : ns[2]);
+            const uint8_t *base = g0 ? sf0 : (g1 ? sf1 : sf2);
+            // (slabs past the wave's last: any valid address; their dwords are never read)
+            dma4(i < cnt ? base + ((size_t)sl + (size_t)(n0 >> 7) * nsg) * 512 + aoff : safe, img_lds + k * 256);
+        }
+        m0_restore(keep_m0);
+        simg = img + 4 * li + h;
+    }
 
     // ---- everything that depends on (segment, lane) only ----
     // piece k of a 16-row tile with C chunks per row: lane p fetches (row, chunk); its 16 bytes land at LDS byte 1024 k + 16 p
@@ -272,8 +327,10 @@ __device__ __forceinline__ void stream_body(const GemmArgs &a, const dq::QuantIn
         const unsigned base = ring + d * RG::SLOT;
         // the scale atoms first: they come from L2 and would otherwise queue behind the slab's weight tiles
         if constexpr (!(MM_STREAM_DBG & 2)) {
-            q.sw = load_atom(rsw[G], sf_lane, (s + (n0 >> 7) * ns[G]) * 512);
-            if constexpr (!QUANT) q.sx = load_atom(rsx[G], sf_lane, s * 512);
+            if constexpr (!QUANT) {
+                q.sw = load_atom(rsw[G], sf_lane, (s + (n0 >> 7) * ns[G]) * 512);
+                q.sx = load_atom(rsx[G], sf_lane, s * 512);
+            }
         }
         if constexpr (!(MM_STREAM_DBG & 16)) {
 #pragma unroll
@@ -313,13 +370,16 @@ __device__ __forceinline__ void stream_body(const GemmArgs &a, const dq::QuantIn
     // QUANT: this lane's row of the workgroup's own quantized activations (rows past M: row 0 again -- their outputs are never stored)
     dq::LdsMap L = {};
     const uint8_t *qx[3] = {nullptr, nullptr, nullptr}, *qs[3] = {nullptr, nullptr, nullptr};
-    auto consume_g = [&](const Slot &q, int d, auto G_, int s) {
+    auto consume_g = [&](const Slot &q, int d, auto G_, int s, [[maybe_unused]] int i) {
         constexpr int G = decltype(G_)::value, GW = W4 ? 0 : G;
         const uint8_t *base = ringp + d * RG::SLOT;
         // scales: the dword of (row, row group) from the lane that loaded it, shifted to this lane's K block
         int sx[T16], sw[F];
 #pragma unroll
-        for (int f = 0; f < F; ++f) sw[f] = __builtin_amdgcn_ds_bpermute(sfw_src[f], sfw_hi[f] ? q.sw[1] : q.sw[0]) >> sh;
+        for (int f = 0; f < F; ++f) {
+            if constexpr (QUANT) sw[f] = (MM_STREAM_DBG & 2) ? 0 : (int)simg[i * (64 * F) + 64 * f];      // (dword 16 F i + 16 f + li of the image, byte h)
+            else sw[f] = __builtin_amdgcn_ds_bpermute(sfw_src[f], sfw_hi[f] ? q.sw[1] : q.sw[0]) >> sh;
+        }
         typename Frag<G>::type xv[T16];
         typename Frag<GW>::type wv[F];
         if constexpr (QUANT) {
@@ -354,14 +414,13 @@ __device__ __forceinline__ void stream_body(const GemmArgs &a, const dq::QuantIn
         else if (j < c2) issue_g(q, d, std::integral_constant<int, 1>{}, j - c1);
         else issue_g(q, d, std::integral_constant<int, 2>{}, j - c2);
     };
-    auto consume = [&](const Slot &q, int d, int j) {
-        if (j < c1) consume_g(q, d, std::integral_constant<int, 0>{}, j);
-        else if (j < c2) consume_g(q, d, std::integral_constant<int, 1>{}, j - c1);
-        else consume_g(q, d, std::integral_constant<int, 2>{}, j - c2);
+    auto consume = [&](const Slot &q, int d, int j, int i) {      // i = (j - wave) / NW
+        if (j < c1) consume_g(q, d, std::integral_constant<int, 0>{}, j, i);
+        else if (j < c2) consume_g(q, d, std::integral_constant<int, 1>{}, j - c1, i);
+        else consume_g(q, d, std::integral_constant<int, 2>{}, j - c2, i);
     };
 
-    // this wave's slabs: j = wave + NW * i, i = 0 .. cnt-1; `shift` phantom steps in front make the step count a multiple of D
-    const int cnt = wave < T ? (T - wave + NW - 1) / NW : 0;
+    // `shift` phantom steps in front make the step count a multiple of D
     const int rounds = (cnt + D - 1) / D, shift = rounds * D - cnt;
     auto slab_of = [&](int step) { const int i = step - shift; return wave + NW * (i > 0 ? i : 0); };
     Slot q[D];
@@ -404,7 +463,7 @@ __device__ __forceinline__ void stream_body(const GemmArgs &a, const dq::QuantIn
             for (int d = 0; d < D; ++d) {
                 const int step = r * D + d;
                 wait_slot<(D - 1) * RG::LOADS>(q[d]);
-                if (step >= shift) consume(q[d], d, slab_of(step));
+                if (step >= shift) consume(q[d], d, slab_of(step), step - shift);
                 MM_DEVICE_ONLY(asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");)   // the slot's fragments are in registers before it is refilled
                 issue(q[d], d, slab_of(step + D));
             }
@@ -413,7 +472,7 @@ __device__ __forceinline__ void stream_body(const GemmArgs &a, const dq::QuantIn
             constexpr int d = decltype(d_)::value;
             const int step = (rounds - 1) * D + d;
             wait_slot<(D - 1 - d) * RG::LOADS>(q[d]);
-            if (step >= shift) consume(q[d], d, slab_of(step));
+            if (step >= shift) consume(q[d], d, slab_of(step), step - shift);
         };
         [&]<int... I>(std::integer_sequence<int, I...>) { (last(std::integral_constant<int, I>{}), ...); }(std::make_integer_sequence<int, D>{});
     }
@@ -593,10 +652,12 @@ static hipError_t launch_quant(const GemmArgs &a, dq::QuantIn qi, hipStream_t st
     }
     if (!RMS && qi.norm_w != nullptr) return hipErrorInvalidValue;       // (a kernel-developer override picked a configuration without a norm variant)
     const int present = (a.K[0] ? 1 : 0) + (a.K[1] ? 1 : 0) + (a.K[2] ? 1 : 0);
-    const size_t red_bytes = (size_t)NW * present * F * 4 * 64 * sizeof(float), ring_bytes = (size_t)NW * D * Ring<F, 1, W4, true>::SLOT;
-    const size_t tail = red_bytes > ring_bytes ? red_bytes : ring_bytes;
     const size_t Kt = (size_t)a.K[0] + a.K[1] + a.K[2];
-    const size_t ops = ((dq::operand_bytes(a.M, a.K) + 15) & ~(size_t)15) + (qi.norm_w != nullptr ? dq::rms_bytes(a.M, a.K) : 0);
+    // [rings | scale image] while the slabs stream, then the reduction image over both
+    const size_t red_bytes = (size_t)NW * present * F * 4 * 64 * sizeof(float);
+    const size_t ring_bytes = (size_t)NW * D * Ring<F, 1, W4, true>::SLOT + scale_image_bytes(F, NW, (int)(Kt >> 7));
+    const size_t tail = red_bytes > ring_bytes ? red_bytes : ring_bytes;
+    const size_t ops = ((dq::operand_bytes(a.M, a.K) + 15) & ~(size_t)15) + (qi.norm_w != nullptr ? ((dq::rms_bytes(a.M, a.K) + 15) & ~(size_t)15) : 0);
     // staged bf16 rows: all M if two workgroups still fit a CU's 160 KB, else as many as one workgroup can hold (at least one)
     constexpr size_t LDS_CU = 160 * 1024, LDS_WG = 156 * 1024;
     size_t rows = qi.mode == 1 ? 0 : a.M;       // (mode 1 quantizes straight from global memory: nothing is staged)
@@ -668,6 +729,15 @@ bool mx_gemm_stream_supported(int M, int N, const int K[3], bool w4) {
 // = 64 KB (fp4 weights: 48 KB).  The supported() predicates budget this worst case so that a shape they accept always launches
 // (they budgeted 48 KB whatever the weight mode).
 constexpr size_t stream_tail_budget(bool w4) { return (w4 ? 48 : 64) * 1024; }
+// ... with the scale image (stream::scale_image_bytes) of the (F, NW) the dispatch below picks for N output features behind the rings
+// (NW * D * SLOT <= 32 KB with fp4 weights, 64 KB without): under the reduction image where that is the larger one
+static size_t quant_tail_budget(int N, size_t Kt, bool w4) {
+    const int cus = device_cus(), T = (int)(Kt >> 7);
+    const size_t simg = (N + 31) / 32 > 2 * cus ? stream::scale_image_bytes(4, 4, T)
+                                                : ((N + 31) / 32 >= cus ? stream::scale_image_bytes(2, 8, T) : stream::scale_image_bytes(1, 8, T));
+    const size_t rings = (w4 ? 32 : 64) * 1024 + simg;
+    return rings > stream_tail_budget(w4) ? rings : stream_tail_budget(w4);
+}
 
 // 1 if mm_qlinear_decode can run on the streaming kernel (the quantized rows, one staged row and the rings fit a workgroup's LDS)
 bool qlinear_stream_supported(int M, int N, const int K[3], bool rms, bool w4) {
@@ -678,9 +748,10 @@ bool qlinear_stream_supported(int M, int N, const int K[3], bool rms, bool w4) {
     const size_t Kt = (size_t)K[0] + K[1] + K[2];
     const size_t norm = rms ? dq::rms_bytes(M, K) : 0;
     if (rms && Kt > (size_t)dq::RMS_MAX_K) return false;
-    if (on == 2 && M >= 1 && M <= 8) return dq::operand_bytes(M, K) + norm + Kt * 2 + stream_tail_budget(w4) + 64 <= 156 * 1024;     // (A/B runs: every shape that fits)
+    const size_t need = dq::operand_bytes(M, K) + norm + Kt * 2 + quant_tail_budget(N, Kt, w4) + 64;
+    if (on == 2 && M >= 1 && M <= 8) return need <= 156 * 1024;     // (A/B runs: every shape that fits)
     if (!on || M < 1 || M > 4 || (N + 31) / 32 < device_cus()) return false;
-    return dq::operand_bytes(M, K) + norm + Kt * 2 + stream_tail_budget(w4) + 64 <= 156 * 1024;
+    return need <= 156 * 1024;
 }
 
 hipError_t launch_qlinear_stream(const void *X, const int16_t *idx, const uint8_t *const W[3], const uint8_t *const SFW[3], int M, int N,
@@ -729,8 +800,8 @@ hipError_t launch_qlinear_stream(const void *X, const int16_t *idx, const uint8_
 // mm_down_activate_decode: down_proj at M <= 4 straight from the bf16 gate | up matrix -- every workgroup computes silu(gate) * up and
 // quantizes it for its own use (the bytes of mm_activate_quantize), K = the intermediate size in natural order
 bool down_activate_stream_supported(int M, int N, const int K[3], bool w4) {
-    (void)N;
-    return M >= 1 && M <= 4 && dq::operand_bytes(M, K) + stream_tail_budget(w4) + 64 <= 156 * 1024;
+    const size_t Kt = (size_t)K[0] + K[1] + K[2];
+    return M >= 1 && M <= 4 && dq::operand_bytes(M, K) + quant_tail_budget(N, Kt, w4) + 64 <= 156 * 1024;
 }
 hipError_t launch_down_activate_stream(const void *GU, const uint8_t *const W[3], const uint8_t *const SFW[3], int M, int N, const int K[3],
                                        bool w4, int round_per_segment, const void *bias, void *D, hipStream_t stream) {
@@ -754,6 +825,9 @@ hipError_t launch_down_activate_stream(const void *GU, const uint8_t *const W[3]
     a.D = (uint16_t *)D;
     const bool wide = (N + 31) / 32 >= device_cus();
     if (wide) return w4 ? launch_quant<2, 2, 8, true>(a, qi, stream) : launch_quant<2, 2, 8, false>(a, qi, stream);
+    // (A deeper ring does nothing here -- seven or fourteen slots, a wave's whole share of K = 14336 in flight at once, measured the same
+    // 10.6 us as three, round 6: the launch is the sum of its vector-memory instructions, not a chain of round trips.  The scale image is
+    // what took 1.6 us off it.)
     return w4 ? launch_quant<1, 3, 8, true>(a, qi, stream) : launch_quant<1, 3, 8, false>(a, qi, stream);
 }
 

@@ -15,7 +15,7 @@ st = torch.cuda.current_stream().cuda_stream
 pp = lambda t: t.data_ptr() if t.numel() else None
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 # MODE (second argument): "matmul" (default: mm_matmul on pre-quantized rows), "decode" (mm_qlinear_decode: the rows are quantized inside
-# every workgroup; `prime` is then that phase), "norm" (mm_rmsnorm_qlinear_decode: + the RMSNorm)
+# every workgroup; `prime` is then that phase), "norm" (mm_rmsnorm_qlinear_decode: + the RMSNorm), "down" (mm_down_activate_decode)
 MODE = sys.argv[2] if len(sys.argv) > 2 else "matmul"
 for name, N, K, split in (("q/o", 4096, 4096, (2048, 128, 1920)), ("gate/up", 14336, 4096, (2048, 128, 1920)), ("gate+up", 28672, 4096, (2048, 128, 1920)), ("down", 4096, 14336, (12288, 1024, 1024))):
     w = (torch.randn((N, K), generator=g) * 0.02).to(torch.bfloat16).to(dev)
@@ -26,7 +26,15 @@ for name, N, K, split in (("q/o", 4096, 4096, (2048, 128, 1920)), ("gate/up", 14
     out = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
     ptrs = [pp(t) for t in (a[0], b[0], a[1], b[1], a[2], b[2], a[3], b[3], a[4], b[4], a[5], b[5])]
     f = lambda: lib.mm_matmul(*ptrs, M, N, *split, 1, 0, None, out.data_ptr(), st)
-    if MODE != "matmul":
+    if MODE == "down":       # mm_down_activate_decode: silu(gate) * up, quantized inside every workgroup (K = the intermediate size)
+        if name != "down":
+            continue
+        gu = torch.randn((M, 2 * K), generator=g).to(torch.bfloat16).to(dev)
+        bd = [pp(t) for t in mixedgemm.downproj_quantize_w4(w, *split)]
+        f = lambda: lib.mm_down_activate_decode(gu.data_ptr(), *bd, M, N, *split, 1, 0, None, out.data_ptr(), st)
+        if f() != 0:
+            print(f"{name:8s} M={M}: {MODE} not supported"); continue
+    elif MODE != "matmul":
         if K > 8192 and MODE == "norm":
             continue
         nw = torch.ones((K,), dtype=torch.bfloat16, device=dev)
