@@ -273,7 +273,7 @@ __device__ __forceinline__ LdsMap quantize_rows_to_lds(const Args &a, uint8_t *s
 template <bool W4, bool RMS = false, int LPG = 1>
 __global__ void __launch_bounds__(NT) qlinear_decode_kernel(Args a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];   // [row stage | opN | opS | opO | scales]
-    __shared__ float red[NW][16][64];
+    __shared__ float red[3][NW][4][64];      // per segment and wave: accumulator registers 0 .. 3 (token rows 0 .. 7)
     // fp4 weights: the first slabs of the workgroup's first feature block are requested in front of the quantization (Prefetch)
     [[maybe_unused]] SegPrefetch<32> pfN, pfS, pfO;
     LdsMap L;
@@ -342,34 +342,34 @@ __global__ void __launch_bounds__(NT) qlinear_decode_kernel(Args a) {
         if (nseg[1]) run_segment<EL_FP6, (W4 ? EL_FP4 : EL_FP6)>(accS, opS, pS, scales + gN, Gt, a.W[1], a.SFW[1], nseg[1], a.M, a.N, n0, a.sfw_row_tiles, r0);
         if (nseg[2]) run_segment<EL_FP8, (W4 ? EL_FP4 : EL_FP8)>(accO, opO, pO, scales + gN + gS, Gt, a.W[2], a.SFW[2], nseg[2], a.M, a.N, n0, a.sfw_row_tiles, r0);
 
-        // cross-wave reduction per segment with the reference's rounding chain (as mx_gemm_skinny.hip)
-        float run[2] = {0.0f, 0.0f};
-        auto reduce = [&](const v16f &acc) {
-            __syncthreads();     // (also: the previous block's / segment's sums have been read)
+        // cross-wave reduction with the reference's rounding chain (as mx_gemm_skinny.hip: per segment the eight waves' sums in wave order, then
+        // D = bf16(segment + D)).  M <= 8: token row m = (i & 3) + 8 (i >> 2) + 4 (l >> 5) of accumulator register i is a row of the launch for
+        // i < 4 only, so a wave leaves those four registers of every present segment side by side and ONE barrier pair serves the three segments
+        // (it was sixteen registers and a barrier pair per segment: six barriers and 48 LDS writes per lane behind every feature block).
+        __syncthreads();     // (the previous block's sums have been read)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) red[wave][i][lane] = acc[i];
-            __syncthreads();
+        for (int i = 0; i < 4; ++i) {
+            if (nseg[0]) red[0][wave][i][lane] = accN[i];
+            if (nseg[1]) red[1][wave][i][lane] = accS[i];
+            if (nseg[2]) red[2][wave][i][lane] = accO[i];
+        }
+        __syncthreads();
+        if (threadIdx.x < 256) {
+            const int e = threadIdx.x, l = e & 63, i = e >> 6;
+            float run = 0.0f;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int e = threadIdx.x + NT * j;
-                float s = 0.0f;
+            for (int g = 0; g < 3; ++g) {
+                if (nseg[g]) {
+                    float s = 0.0f;
 #pragma unroll
-                for (int w = 0; w < NW; ++w) s += (&red[w][0][0])[e];
-                s += run[j];
-                run[j] = a.round_per_segment ? bf16_bits_to_f32(f32_to_bf16_bits(s)) : s;
+                    for (int w = 0; w < NW; ++w) s += (&red[g][w][0][0])[e];
+                    s += run;
+                    run = a.round_per_segment ? bf16_bits_to_f32(f32_to_bf16_bits(s)) : s;
+                }
             }
-        };
-        if (nseg[0]) reduce(accN);
-        if (nseg[1]) reduce(accS);
-        if (nseg[2]) reduce(accO);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int e = threadIdx.x + NT * j;
-            const int l = e & 63, i = (e >> 6) & 15;
-            const int m = (i & 3) + 8 * (i >> 2) + 4 * (l >> 5);
-            const int n = n0 + (l & 31);
+            const int m = i + 4 * (l >> 5), n = n0 + (l & 31);
             if (m < a.M && n < a.N) {
-                uint32_t b = f32_to_bf16_bits(run[j]);
+                uint32_t b = f32_to_bf16_bits(run);
                 if (a.bias != nullptr) b = f32_to_bf16_bits(bf16_bits_to_f32(b) + bf16_bits_to_f32(a.bias[n]));
                 a.D[(size_t)m * a.N + n] = (uint16_t)b;
             }
