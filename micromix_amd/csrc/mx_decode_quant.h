@@ -366,8 +366,8 @@ __device__ __forceinline__ LdsMap quantize_rows_to_lds(const QuantIn &a, uint8_t
 }
 
 // The same phase with ALL of its global loads issued through inline asm before the caller's own untracked loads (`request()`: the
-// first slabs of mx_gemm_stream.hip's DMA ring, AFTER_LOADS vector-memory instructions when it returns true), and ONE counted wait:
-// the rows and indices are older than the ring, so vmcnt(AFTER_LOADS) certifies them while the weights stay in flight -- they are
+// first slabs of mx_gemm_stream.hip's DMA ring and its scale image; it returns the number of vector-memory instructions it issued -- at
+// most 63, wave-uniform, 0: none), and ONE counted wait: the rows and indices are older than those, so vmcnt(that number) certifies them while the weights stay in flight -- they are
 // requested ~1 us earlier than from the hook of quantize_rows_to_lds, which has to wait for the staged rows first.
 // Preconditions (QuantIn::early, set by the launcher: early_fits): stage_rows >= M and at most NPASS (row, group, half) slots per thread,
 // 2 M K / 32 <= NPASS NT -- which bounds the rows at EARLY_RL and the norm's weight vector at EARLY_WL 16-byte chunks per thread and pass.
@@ -385,9 +385,21 @@ __device__ __forceinline__ dq_v4u gload16(const void *p) {
 // NPASS: slots per thread.  1 on the eight-wave kernels, whose register count decides how many workgroups a CU holds; 2 on the four-wave
 // 64-feature kernels (two workgroups per CU either way), where it keeps M = 2 at K = 4096 on this path (fused gate + up 13.8 us; through the
 // staged path 16.3).
+// s_waitcnt vmcnt(n) for a wave-uniform n known at run time only (0 .. 63: the immediate is picked by six scalar compares)
+template <int LO, int HI>
+__device__ __forceinline__ void wait_vmcnt_range(int n) {
+    if constexpr (LO == HI) {
+        MM_DQ_DEVICE_ONLY(asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LO) : "memory");)
+    } else {
+        constexpr int MID = (LO + HI) / 2;
+        if (n <= MID) wait_vmcnt_range<LO, MID>(n);
+        else wait_vmcnt_range<MID + 1, HI>(n);
+    }
+}
+__device__ __forceinline__ void wait_vmcnt(int n) { wait_vmcnt_range<0, 63>(n < 0 ? 0 : (n > 63 ? 63 : n)); }
 __host__ __device__ inline bool early_fits(int M, int Kt, int NT, int npass) { return 2 * (size_t)M * (size_t)(Kt >> 5) <= (size_t)NT * npass; }
-template <int NT, int AFTER_LOADS, bool RMS, int NPASS, class Request>
-__device__ __forceinline__ LdsMap quantize_rows_early(const QuantIn &a, uint8_t *smem, Request request) {
+template <int NT, bool RMS, int NPASS, class Request, class Landed>
+__device__ __forceinline__ LdsMap quantize_rows_early(const QuantIn &a, uint8_t *smem, Request request, Landed landed) {
     const int Kt = a.K[0] + a.K[1] + a.K[2], Gt = Kt >> 5;
     const int gN = a.K[0] >> 5, gS = a.K[1] >> 5;
     const int pN = a.K[0] >> 1, pS = (a.K[1] >> 2) * 3, pO = a.K[2];
@@ -438,9 +450,11 @@ __device__ __forceinline__ LdsMap quantize_rows_early(const QuantIn &a, uint8_t 
             wq[k] = gload16(reinterpret_cast<const uint4 *>(a.norm_w) + (c < (Kt >> 3) ? c : 0));
         }
     }
-    const bool requested = request();
-    if (requested) { MM_DQ_DEVICE_ONLY(asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AFTER_LOADS) : "memory");) }
-    else { MM_DQ_DEVICE_ONLY(asm volatile("s_waitcnt vmcnt(0)" ::: "memory");) }
+    wait_vmcnt(request());      // (everything older than the caller's requests: this phase's loads)
+    // `landed()`: requests of the caller's that may NOT travel in front of any wave's rows -- a CU's memory pipe returns its waves' loads in
+    // issue order, so a slow request (scale bytes from HBM) issued before a later wave's rows holds those up, and the phase's barrier waits
+    // for every wave's.  Here this wave's loads are home and every other wave's have long been issued.
+    landed();
 #pragma unroll
     for (int p = 0; p < NPASS; ++p) { MM_DQ_DEVICE_ONLY(asm volatile("" : "+v"(iq[p][0]), "+v"(iq[p][1]));) }
 #pragma unroll
@@ -582,15 +596,15 @@ __device__ __forceinline__ LdsMap activate_rows_to_lds(const QuantIn &a, uint8_t
 }
 
 // The same with the gate | up values loaded through inline asm IN FRONT of the caller's own untracked loads (`request()`: the first slabs
-// of the weight ring, AFTER_LOADS vector-memory instructions when it returns true) and ONE counted wait -- as quantize_rows_early: the
+// of the weight ring; it returns the number of vector-memory instructions it issued) and ONE counted wait -- as quantize_rows_early: the
 // weights are requested ~1 us earlier than from the hook above, which has to wait for the values first (round 6).
 // Precondition (QuantIn::early with mode 1, set by the launcher): ONE pass, M * K / 32 <= NT.
 // (Round 6, measured and dropped: FOUR lanes per group -- a lane owns one 16-byte chunk of gate and of up, the absmax meets by DPP, every
 // load instruction covers contiguous runs of 256 bytes.  down_proj at M = 1 the same 9.4 us, M = 2 11.0 -> 12.4, M = 4 13.7 -> 17.7: with
 // K = 14336 one lane per group already keeps 448 of 512 threads busy, so a thread's chain of silu does not get shorter, there are only
 // more passes; lane-contiguous loads alone were worth 0.35 us.)
-template <int NT, int AFTER_LOADS, class Request>
-__device__ __forceinline__ LdsMap activate_rows_early(const QuantIn &a, uint8_t *smem, Request request) {
+template <int NT, class Request, class Landed>
+__device__ __forceinline__ LdsMap activate_rows_early(const QuantIn &a, uint8_t *smem, Request request, Landed landed) {
     const int Kt = a.K[0] + a.K[1] + a.K[2], Gt = Kt >> 5;
     const int gN = a.K[0] >> 5, gS = a.K[1] >> 5;
     const int pN = a.K[0] >> 1, pS = (a.K[1] >> 2) * 3, pO = a.K[2];
@@ -606,9 +620,11 @@ __device__ __forceinline__ LdsMap activate_rows_early(const QuantIn &a, uint8_t 
         qa[i] = gload16(pa + i);
         qb[i] = gload16(pa + 16 + i);
     }
-    const bool requested = request();
-    if (requested) { MM_DQ_DEVICE_ONLY(asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AFTER_LOADS) : "memory");) }
-    else { MM_DQ_DEVICE_ONLY(asm volatile("s_waitcnt vmcnt(0)" ::: "memory");) }
+    wait_vmcnt(request());      // (everything older than the caller's requests: this phase's loads)
+    // `landed()`: requests of the caller's that may NOT travel in front of any wave's rows -- a CU's memory pipe returns its waves' loads in
+    // issue order, so a slow request (scale bytes from HBM) issued before a later wave's rows holds those up, and the phase's barrier waits
+    // for every wave's.  Here this wave's loads are home and every other wave's have long been issued.
+    landed();
 #pragma unroll
     for (int i = 0; i < 4; ++i) { MM_DQ_DEVICE_ONLY(asm volatile("" : "+v"(qa[i]), "+v"(qb[i]));) }
     if (live) {

@@ -239,9 +239,14 @@ __device__ __forceinline__ void stream_body(const GemmArgs &a, const dq::QuantIn
 
     // this wave's slabs: j = wave + NW * i, i = 0 .. cnt-1
     const int cnt = wave < T ? (T - wave + NW - 1) / NW : 0;
-    // QUANT: the wave's scale image (see scale_image_bytes) is requested before anything else, so every later wait covers it
+    // QUANT: the wave's scale image (see scale_image_bytes).  WHEN it is requested matters: a CU's memory pipe returns its waves' loads in
+    // issue order and these come from HBM / the Infinity Cache.  In front of the activation rows (all waves at once, at the start) the
+    // quantization phase grew by 0.5 us; behind a wave's rows but possibly in front of a later wave's by 0.8-1.3 (tools/stream_clock.py).
+    // So: once the wave's own rows have landed (the early reorder phase's `landed` hook; fused gate + up at M = 1 12.8 -> 12.0 us against
+    // in front), in front for the other phases (below); the loop starts with one wait for everything requested under the phase.
     [[maybe_unused]] const uint8_t *simg = nullptr;       // + 4 (16 F k' + row) + K block: the scale byte of (slab i = 4 / F k + k', row) -- see consume_g
-    if constexpr (QUANT && !(MM_STREAM_DBG & 2)) {
+    auto request_scales = [&]() {
+      if constexpr (QUANT && !(MM_STREAM_DBG & 2)) {
         constexpr int R = 16 * F, SPI = 64 / R;
         const int wimg = scale_image_wave_bytes(F, NW, T);
         const uint8_t *img = smem + NW * D * RG::SLOT + wave * wimg;
@@ -250,23 +255,26 @@ __device__ __forceinline__ void stream_body(const GemmArgs &a, const dq::QuantIn
         const int aoff = (n & 31) * 16 + ((n >> 5) & 3) * 4;      // (atom row n & 31, row group (n >> 5) & 3): the dword of weight row n
         // (the three pointers as opaque scalars: hipcc otherwise turns the per-lane select between them into a per-lane LOAD from the
         // kernel-argument segment, with a wait for every outstanding load behind it, in every trip of the loop)
+        // (the slab counts likewise: the select between ns[0 .. 2] became an index into a copy of the array in scratch)
         const uint8_t *sf0 = a.SFW[0], *sf1 = a.SFW[1], *sf2 = a.SFW[2];
-        MM_DEVICE_ONLY(asm volatile("" : "+s"(sf0), "+s"(sf1), "+s"(sf2));)
-        const uint8_t *const safe = ns[0] ? sf0 : (ns[1] ? sf1 : sf2);
+        int ns0 = ns[0], ns1 = ns[1], ns2 = ns[2];
+        MM_DEVICE_ONLY(asm volatile("" : "+s"(sf0), "+s"(sf1), "+s"(sf2), "+s"(ns0), "+s"(ns1), "+s"(ns2));)
+        const uint8_t *const safe = ns0 ? sf0 : (ns1 ? sf1 : sf2);
         const unsigned keep_m0 = m0_save();
 #pragma unroll 1
         for (int k = 0; k * SPI < cnt; ++k) {
             const int i = k * SPI + qd, j = wave + NW * i;
             // (selects, not arrays indexed by the lane's segment: those would live in scratch)
             const bool g0 = j < c1, g1 = j < c2;
-            const int sl = j - (g0 ? 0 : (g1 ? c1 : c2)), nsg = g0 ? ns[0] : (g1 ? ns[1] : ns[2]);
+            const int sl = j - (g0 ? 0 : (g1 ? c1 : c2)), nsg = g0 ? ns0 : (g1 ? ns1 : ns2);
             const uint8_t *base = g0 ? sf0 : (g1 ? sf1 : sf2);
             // (slabs past the wave's last: any valid address; their dwords are never read)
             dma4(i < cnt ? base + ((size_t)sl + (size_t)(n0 >> 7) * nsg) * 512 + aoff : safe, img_lds + k * 256);
         }
         m0_restore(keep_m0);
-        simg = img + 4 * li + h;
-    }
+      }
+    };
+    if constexpr (QUANT && !(MM_STREAM_DBG & 2)) simg = smem + NW * D * RG::SLOT + wave * scale_image_wave_bytes(F, NW, T) + 4 * li + h;
 
     // ---- everything that depends on (segment, lane) only ----
     // piece k of a 16-row tile with C chunks per row: lane p fetches (row, chunk); its 16 bytes land at LDS byte 1024 k + 16 p
@@ -426,18 +434,22 @@ __device__ __forceinline__ void stream_body(const GemmArgs &a, const dq::QuantIn
     Slot q[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) q[d].sw = q[d].sx = v2i{0, 0};
-    auto prime = [&]() {
+    auto prime = [&]() {      // returns the number of vector-memory instructions it issued (the early quantization phases count them)
         if (cnt > 0) {
 #pragma unroll
             for (int d = 0; d < D; ++d) issue(q[d], d, slab_of(d));
         }
-        return cnt > 0;
+        return cnt > 0 ? D * RG::LOADS : 0;
     };
+    auto scales = [&]() { if (cnt > 0) request_scales(); };
     if constexpr (QUANT) {
         // (the activation mode has no norm: its 32 + 32 registers stay out of the norm kernels' allocation)
-        if (!RMS && qi.mode == 1 && qi.early) L = dq::activate_rows_early<NT, D * RG::LOADS>(qi, smem_all, prime);
+        // (the staged phases and the activation mode -- whose own loads are many and whose arithmetic is long -- take the image in front:
+        // down_proj at M = 1 9.2 against 9.3 us, M = 4 13.7 against 14.8)
+        if (!qi.early || qi.mode == 1) scales();
+        if (!RMS && qi.mode == 1 && qi.early) L = dq::activate_rows_early<NT>(qi, smem_all, prime, [] {});
         else if (!RMS && qi.mode == 1) L = dq::activate_rows_to_lds<NT>(qi, smem_all, [&]() { prime(); });
-        else if (qi.early) L = dq::quantize_rows_early<NT, D * RG::LOADS, RMS, EARLY_NPASS<NW>>(qi, smem_all, prime);
+        else if (qi.early) L = dq::quantize_rows_early<NT, RMS, EARLY_NPASS<NW>>(qi, smem_all, prime, scales);
         // (whatever fits one pass of lane pairs went the early way: the staged path runs one lane per group -- except in the norm's
         // eight-wave 32-feature kernel, whose register count decides between one and two workgroups per CU)
         else L = dq::quantize_rows_to_lds<NT, RMS, (RMS && NW == 8 && F == 2) ? 2 : 1>(qi, smem_all, [&]() { prime(); });
@@ -458,6 +470,9 @@ __device__ __forceinline__ void stream_body(const GemmArgs &a, const dq::QuantIn
 #endif
     if (cnt > 0) {
         MM_STAMP(1);
+        // (QUANT: the scale image is younger than the ring's first slabs, the counted waits below would not cover it; all of it was
+        // requested a quantization phase ago)
+        if constexpr (QUANT) { MM_DEVICE_ONLY(asm volatile("s_waitcnt vmcnt(0)" ::: "memory");) }
         for (int r = 0; r + 1 < rounds; ++r) {
 #pragma unroll
             for (int d = 0; d < D; ++d) {
@@ -548,6 +563,37 @@ __device__ __forceinline__ void stream_body(const GemmArgs &a, const dq::QuantIn
         });
         __syncthreads();
         MM_STAMP(3);
+        if constexpr (T16 == 1) {
+            // One token tile: only M of a tile's 16 token rows exist.  The live outputs are numbered through -- (tile f, token m, feature
+            // column) = 16 M per tile -- and spread over the workgroup's threads: at M = 1 on 64 features that is one output for each lane of
+            // wave 0 instead of four passes over a 1024-entry image of which 64 are live (`reduce+store` 1.7 us of the fused gate + up launch,
+            // tools/stream_clock.py).  The same sums in the same order: per segment the waves' partial sums in wave order, then the chain.
+            const int rows = a.M < 16 ? a.M : 16, nlive = ACC * 16 * rows;
+            for (int t = threadIdx.x; t < nlive; t += NT) {
+                const int f = t / (16 * rows), rem = t - f * 16 * rows, m = rem >> 4, col = rem & 15;
+                const int o = f * 256 + (m & 3) * 64 + 16 * (m >> 2) + col;      // register m & 3 of lane 16 (m >> 2) + col of tile f
+                float run1 = 0.0f;
+                for (int sl = 0; sl < P; ++sl) {
+                    float s = 0.0f;
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) s += red[((size_t)w * P + sl) * IMG + o];
+                    s += run1;
+                    run1 = a.round_per_segment ? bf16_bits_to_f32(f32_to_bf16_bits(s)) : s;
+                }
+                const int n = n0 + 16 * f + col;
+                if (n < a.N) {
+                    if (a.out_f32) {
+                        reinterpret_cast<float *>(a.D)[(size_t)m * a.N + n] = run1;
+                    } else {
+                        uint32_t b = f32_to_bf16_bits(run1);
+                        if (a.bias != nullptr) b = f32_to_bf16_bits(bf16_bits_to_f32(b) + bf16_bits_to_f32(a.bias[n]));
+                        a.D[(size_t)m * a.N + n] = (uint16_t)b;
+                    }
+                }
+            }
+            MM_STAMP(4);
+            return;
+        }
         // Segment by segment, the thread's PER outputs side by side: the PER * NW reads of a segment are independent and travel together,
         // then the chain.  (Round 6: with the outputs outside and the segments inside, every segment of every output was its own LDS
         // round trip -- 12 in a row for 64 features x 3 segments: `reduce+store` 1.9 us of a 14 us launch, tools/stream_clock.py.)
