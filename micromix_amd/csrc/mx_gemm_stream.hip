@@ -880,8 +880,8 @@ hipError_t launch_down_activate_stream(const void *GU, const uint8_t *const W[3]
     const bool wide = (N + 31) / 32 >= device_cus();
     if (wide) return w4 ? launch_quant<2, 2, 8, true>(a, qi, stream) : launch_quant<2, 2, 8, false>(a, qi, stream);
     // (A deeper ring does nothing here -- seven or fourteen slots, a wave's whole share of K = 14336 in flight at once, measured the same
-    // 10.6 us as three, round 6: the launch is the sum of its vector-memory instructions, not a chain of round trips.  The scale image is
-    // what took 1.6 us off it.)
+    // 10.6 us as three, round 6, and with the weights coming from HBM 11.6 against 11.5: the launch is the sum of its vector-memory
+    // instructions, not a chain of round trips.  The scale image is what took 1.6 us off it.)
     return w4 ? launch_quant<1, 3, 8, true>(a, qi, stream) : launch_quant<1, 3, 8, false>(a, qi, stream);
 }
 
