@@ -162,8 +162,8 @@ __device__ __forceinline__ void static_for(Fn &&fn) {
 }
 
 // one slot of a wave's LDS ring: F weight tiles (one 1 KB piece each with fp4 weights, two otherwise), T16 activation tiles of two pieces
-// (QUANT: the workgroup quantizes the activation rows itself, mx_decode_quant.h -- no activation tiles, no activation scale atom, and the
-// weights' scales come from the wave's scale image, see scale_image_bytes: no scale atom per slab either)
+// (QUANT: the workgroup quantizes the activation rows itself, mx_decode_quant.h -- no activation tiles, no activation scale atom.  QUANT or
+// one token tile: the scales come from the wave's scale images, see scale_image_bytes: no scale atoms per slab)
 template <int F, int T16, bool W4, bool QUANT = false>
 struct Ring {
     static constexpr int WP = W4 ? 1 : 2;
@@ -171,7 +171,7 @@ struct Ring {
     // vector-memory instructions of a slab, at least: the second piece of an activation tile is requested only where it holds rows the
     // launch has (fp4 tiles are one piece; M <= 8: rows 0 .. 7 sit in the first piece of every format).  The counted waits use this
     // minimum -- with longer slabs behind it a wait lets at most one instruction fewer stay in flight, never one too many.
-    static constexpr int LOADS = ((MM_STREAM_DBG & 16) ? 0 : F * WP) + ((MM_STREAM_DBG & 1) || QUANT ? 0 : T16) + ((MM_STREAM_DBG & 2) || QUANT ? 0 : 2);
+    static constexpr int LOADS = ((MM_STREAM_DBG & 16) ? 0 : F * WP) + ((MM_STREAM_DBG & 1) || QUANT ? 0 : T16) + ((MM_STREAM_DBG & 2) || QUANT || T16 == 1 ? 0 : 2);
 };
 
 // chunks per row of a segment's 128-deep slab: fp4 4, fp6 6, fp8 8 (x 16 bytes)
@@ -202,6 +202,11 @@ __host__ __device__ constexpr int scale_image_wave_bytes(int F, int NW, int T) {
     return (per_wave + spi - 1) / spi * 256;
 }
 __host__ __device__ constexpr int scale_image_bytes(int F, int NW, int T) { return NW * scale_image_wave_bytes(F, NW, T); }
+// both images of a launch without the quantization (weights' rows 16 F, activations' 16 T16): one token tile only, see stream_body
+__host__ __device__ constexpr int scale_images_bytes(int F, int T16, int NW, int T) {
+    return T16 == 1 ? scale_image_bytes(F, NW, T) + scale_image_bytes(T16, NW, T) : 0;
+}
+constexpr int STREAM_LDS_MAX = 160 * 1024;      // (the 64-token configuration on 16 features uses all of a CU's LDS)
 // one global_load_lds_dword: lane l's dword at `p` -> LDS byte lds + 4 l (M0 = lds; counted by vmcnt like the ring's DMA)
 // (M0 is saved and restored by the caller, once around its loop: m0_save / m0_restore)
 __device__ __forceinline__ void dma4(const uint8_t *p, unsigned lds) {
@@ -239,42 +244,58 @@ __device__ __forceinline__ void stream_body(const GemmArgs &a, const dq::QuantIn
 
     // this wave's slabs: j = wave + NW * i, i = 0 .. cnt-1
     const int cnt = wave < T ? (T - wave + NW - 1) / NW : 0;
-    // QUANT: the wave's scale image (see scale_image_bytes).  WHEN it is requested matters: a CU's memory pipe returns its waves' loads in
-    // issue order and these come from HBM / the Infinity Cache.  In front of the activation rows (all waves at once, at the start) the
-    // quantization phase grew by 0.5 us; behind a wave's rows but possibly in front of a later wave's by 0.8-1.3 (tools/stream_clock.py).
-    // So: once the wave's own rows have landed (the early reorder phase's `landed` hook; fused gate + up at M = 1 12.8 -> 12.0 us against
-    // in front), in front for the other phases (below); the loop starts with one wait for everything requested under the phase.
-    [[maybe_unused]] const uint8_t *simg = nullptr;       // + 4 (16 F k' + row) + K block: the scale byte of (slab i = 4 / F k + k', row) -- see consume_g
+    // The wave's scale images (see scale_image_bytes): QUANT kernels and, without the quantization, launches of one token tile (M <= 16:
+    // there the two atoms were two of a slab's five or six vector-memory instructions; with more token tiles the images would cost the
+    // second workgroup its place in the CU's LDS).  The weights' image [k][lane = (slab 4 / F k + k', weight row)], then -- not QUANT -- the
+    // activations' [k][lane = (slab 4 k + k', token row)], behind the rings.
+    // QUANT: WHEN the image is requested matters: a CU's memory pipe returns its waves' loads in issue order and these come from HBM / the
+    // Infinity Cache.  In front of the activation rows (all waves at once, at the start) the quantization phase grew by 0.5 us; behind a
+    // wave's rows but possibly in front of a later wave's by 0.8-1.3 (tools/stream_clock.py).  So: once the wave's own rows have landed
+    // (the early reorder phase's `landed` hook; fused gate + up at M = 1 12.8 -> 12.0 us against in front), in front for the other phases
+    // (below); the loop starts with one wait for everything requested under the phase.  Not QUANT: in front of the ring's first slabs.
+    constexpr bool SIMG = (QUANT || T16 == 1) && !(MM_STREAM_DBG & 2);
+    [[maybe_unused]] const uint8_t *simg = nullptr, *simgx = nullptr;       // + 64 F i + 64 f (+ 64 i): the scale byte of (slab i, this lane's row and K block) -- see consume_g
     auto request_scales = [&]() {
-      if constexpr (QUANT && !(MM_STREAM_DBG & 2)) {
-        constexpr int R = 16 * F, SPI = 64 / R;
-        const int wimg = scale_image_wave_bytes(F, NW, T);
-        const uint8_t *img = smem + NW * D * RG::SLOT + wave * wimg;
-        const unsigned img_lds = __builtin_amdgcn_readfirstlane(lds_address(img));
-        const int qd = lane / R, n = n0 + (lane % R);
-        const int aoff = (n & 31) * 16 + ((n >> 5) & 3) * 4;      // (atom row n & 31, row group (n >> 5) & 3): the dword of weight row n
-        // (the three pointers as opaque scalars: hipcc otherwise turns the per-lane select between them into a per-lane LOAD from the
-        // kernel-argument segment, with a wait for every outstanding load behind it, in every trip of the loop)
-        // (the slab counts likewise: the select between ns[0 .. 2] became an index into a copy of the array in scratch)
-        const uint8_t *sf0 = a.SFW[0], *sf1 = a.SFW[1], *sf2 = a.SFW[2];
-        int ns0 = ns[0], ns1 = ns[1], ns2 = ns[2];
-        MM_DEVICE_ONLY(asm volatile("" : "+s"(sf0), "+s"(sf1), "+s"(sf2), "+s"(ns0), "+s"(ns1), "+s"(ns2));)
-        const uint8_t *const safe = ns0 ? sf0 : (ns1 ? sf1 : sf2);
+      if constexpr (SIMG) {
         const unsigned keep_m0 = m0_save();
+        // one image: `rows16` 16-row tiles per slab starting at row `row0`, in 128-row scale tile `tile` (a segment's atoms: [tile][slab]); segment bases b0 .. b2
+        auto gather = [&](auto rows16_, const uint8_t *img, int row0, int tile, const uint8_t *b0, const uint8_t *b1, const uint8_t *b2) {
+            constexpr int R = 16 * decltype(rows16_)::value, SPI = 64 / R;
+            const unsigned img_lds = __builtin_amdgcn_readfirstlane(lds_address(img));
+            const int qd = lane / R, n = row0 + (lane % R);
+            const int aoff = (n & 31) * 16 + ((n >> 5) & 3) * 4;      // (atom row n & 31, row group (n >> 5) & 3): the dword of row n
+            // (the three pointers as opaque scalars: hipcc otherwise turns the per-lane select between them into a per-lane LOAD from the
+            // kernel-argument segment, with a wait for every outstanding load behind it, in every trip of the loop; the slab counts
+            // likewise: the select between ns[0 .. 2] became an index into a copy of the array in scratch)
+            int ns0 = ns[0], ns1 = ns[1], ns2 = ns[2];
+            MM_DEVICE_ONLY(asm volatile("" : "+s"(b0), "+s"(b1), "+s"(b2), "+s"(ns0), "+s"(ns1), "+s"(ns2));)
+            const uint8_t *const safe = ns0 ? b0 : (ns1 ? b1 : b2);
 #pragma unroll 1
-        for (int k = 0; k * SPI < cnt; ++k) {
-            const int i = k * SPI + qd, j = wave + NW * i;
-            // (selects, not arrays indexed by the lane's segment: those would live in scratch)
-            const bool g0 = j < c1, g1 = j < c2;
-            const int sl = j - (g0 ? 0 : (g1 ? c1 : c2)), nsg = g0 ? ns0 : (g1 ? ns1 : ns2);
-            const uint8_t *base = g0 ? sf0 : (g1 ? sf1 : sf2);
-            // (slabs past the wave's last: any valid address; their dwords are never read)
-            dma4(i < cnt ? base + ((size_t)sl + (size_t)(n0 >> 7) * nsg) * 512 + aoff : safe, img_lds + k * 256);
+            for (int k = 0; k * SPI < cnt; ++k) {
+                const int i = k * SPI + qd, j = wave + NW * i;
+                // (selects, not arrays indexed by the lane's segment: those would live in scratch)
+                const bool g0 = j < c1, g1 = j < c2;
+                const int sl = j - (g0 ? 0 : (g1 ? c1 : c2)), nsg = g0 ? ns0 : (g1 ? ns1 : ns2);
+                const uint8_t *base = g0 ? b0 : (g1 ? b1 : b2);
+                // (slabs past the wave's last: any valid address; their dwords are never read)
+                dma4(i < cnt ? base + ((size_t)tile * nsg + (size_t)sl) * 512 + aoff : safe, img_lds + k * 256);
+            }
+        };
+        const int wimg = scale_image_wave_bytes(F, NW, T);
+        const uint8_t *img = smem + NW * D * RG::SLOT;
+        gather(std::integral_constant<int, F>{}, img + wave * wimg, n0, n0 >> 7, a.SFW[0], a.SFW[1], a.SFW[2]);
+        if constexpr (!QUANT) {
+            const int ximg = scale_image_wave_bytes(T16, NW, T);
+            gather(std::integral_constant<int, T16>{}, img + NW * wimg + wave * ximg, 0, 0, a.SFX[0], a.SFX[1], a.SFX[2]);
         }
         m0_restore(keep_m0);
       }
     };
-    if constexpr (QUANT && !(MM_STREAM_DBG & 2)) simg = smem + NW * D * RG::SLOT + wave * scale_image_wave_bytes(F, NW, T) + 4 * li + h;
+    if constexpr (SIMG) {
+        const int wimg = scale_image_wave_bytes(F, NW, T);
+        simg = smem + NW * D * RG::SLOT + wave * wimg + 4 * li + h;
+        if constexpr (!QUANT) simgx = smem + NW * D * RG::SLOT + NW * wimg + wave * scale_image_wave_bytes(T16, NW, T) + 4 * li + h;
+    }
 
     // ---- everything that depends on (segment, lane) only ----
     // piece k of a 16-row tile with C chunks per row: lane p fetches (row, chunk); its 16 bytes land at LDS byte 1024 k + 16 p
@@ -335,7 +356,7 @@ __device__ __forceinline__ void stream_body(const GemmArgs &a, const dq::QuantIn
         const unsigned base = ring + d * RG::SLOT;
         // the scale atoms first: they come from L2 and would otherwise queue behind the slab's weight tiles
         if constexpr (!(MM_STREAM_DBG & 2)) {
-            if constexpr (!QUANT) {
+            if constexpr (!SIMG) {
                 q.sw = load_atom(rsw[G], sf_lane, (s + (n0 >> 7) * ns[G]) * 512);
                 q.sx = load_atom(rsx[G], sf_lane, s * 512);
             }
@@ -385,7 +406,8 @@ __device__ __forceinline__ void stream_body(const GemmArgs &a, const dq::QuantIn
         int sx[T16], sw[F];
 #pragma unroll
         for (int f = 0; f < F; ++f) {
-            if constexpr (QUANT) sw[f] = (MM_STREAM_DBG & 2) ? 0 : (int)simg[i * (64 * F) + 64 * f];      // (dword 16 F i + 16 f + li of the image, byte h)
+            if constexpr (SIMG) sw[f] = (int)simg[i * (64 * F) + 64 * f];      // (dword 16 F i + 16 f + li of the image, byte h)
+            else if constexpr (QUANT || T16 == 1) sw[f] = 0;                   // (MM_STREAM_DBG & 2)
             else sw[f] = __builtin_amdgcn_ds_bpermute(sfw_src[f], sfw_hi[f] ? q.sw[1] : q.sw[0]) >> sh;
         }
         typename Frag<G>::type xv[T16];
@@ -404,7 +426,11 @@ __device__ __forceinline__ void stream_body(const GemmArgs &a, const dq::QuantIn
             }
         } else {
 #pragma unroll
-            for (int t = 0; t < T16; ++t) sx[t] = __builtin_amdgcn_ds_bpermute(sfx_src[t], t >= 2 ? q.sx[1] : q.sx[0]) >> sh;
+            for (int t = 0; t < T16; ++t) {
+                if constexpr (SIMG) sx[t] = (int)simgx[i * (64 * T16) + 64 * t];
+                else if constexpr (T16 == 1) sx[t] = 0;                        // (MM_STREAM_DBG & 2)
+                else sx[t] = __builtin_amdgcn_ds_bpermute(sfx_src[t], t >= 2 ? q.sx[1] : q.sx[0]) >> sh;
+            }
 #pragma unroll
             for (int t = 0; t < T16; ++t) xv[t] = frag(base + RG::W_BYTES + t * 2048, std::integral_constant<int, G>{});
         }
@@ -461,6 +487,7 @@ __device__ __forceinline__ void stream_body(const GemmArgs &a, const dq::QuantIn
         qs[1] = qs[0] + L.gN;
         qs[2] = qs[1] + L.gS;
     } else {
+        scales();      // (older than the ring's first slabs: the first step's counted wait covers the images)
         prime();
     }
     // the accumulators are cleared HERE, behind the quantization phase: nothing asm-owned is live while the compiler allocates that
@@ -646,12 +673,14 @@ __global__ void __launch_bounds__(64 * NW) mx_gemm_stream_kernel(GemmArgs a) { s
 template <int F, int T16, int D, int NW, bool W4>
 static hipError_t launch_one(const GemmArgs &a, hipStream_t stream) {
     const int present = (a.K[0] ? 1 : 0) + (a.K[1] ? 1 : 0) + (a.K[2] ? 1 : 0);
-    const int red_bytes = NW * (F * T16 >= 8 ? 1 : present) * F * T16 * 4 * 64 * (int)sizeof(float), stage_bytes = NW * D * Ring<F, T16, W4>::SLOT;
+    // [rings | scale images] while the slabs stream, then the reduction image over both
+    const int red_bytes = NW * (F * T16 >= 8 ? 1 : present) * F * T16 * 4 * 64 * (int)sizeof(float);
+    const int stage_bytes = NW * D * Ring<F, T16, W4>::SLOT + scale_images_bytes(F, T16, NW, (a.K[0] + a.K[1] + a.K[2]) >> 7);
     const int lds = red_bytes > stage_bytes ? red_bytes : stage_bytes;
+    if (lds > STREAM_LDS_MAX) return hipErrorInvalidValue;      // (mx_gemm_stream_supported keeps callers away from this)
     static DynamicLdsOnce once;
     if (lds > 65536) {
-        constexpr int MAX_RED = NW * (F * T16 >= 8 ? 1 : 3) * F * T16 * 1024, MAX_STAGE = NW * D * Ring<F, T16, W4>::SLOT;
-        hipError_t e = once.ensure(reinterpret_cast<const void *>(mx_gemm_stream_kernel<F, T16, D, NW, W4>), MAX_RED > MAX_STAGE ? MAX_RED : MAX_STAGE);
+        hipError_t e = once.ensure(reinterpret_cast<const void *>(mx_gemm_stream_kernel<F, T16, D, NW, W4>), STREAM_LDS_MAX);
         if (e != hipSuccess) return e;
     }
     const int blocks = (a.N + 16 * F - 1) / (16 * F);
@@ -671,12 +700,13 @@ template <int F, int T16, int D, int NW, bool W4>
 static hipError_t launch_grouped_one(const GroupedGemmArgs &ga, hipStream_t stream) {
     const GemmArgs &a = ga.g[0];
     const int present = (a.K[0] ? 1 : 0) + (a.K[1] ? 1 : 0) + (a.K[2] ? 1 : 0);
-    const int red_bytes = NW * (F * T16 >= 8 ? 1 : present) * F * T16 * 4 * 64 * (int)sizeof(float), stage_bytes = NW * D * Ring<F, T16, W4>::SLOT;
+    const int red_bytes = NW * (F * T16 >= 8 ? 1 : present) * F * T16 * 4 * 64 * (int)sizeof(float);
+    const int stage_bytes = NW * D * Ring<F, T16, W4>::SLOT + scale_images_bytes(F, T16, NW, (a.K[0] + a.K[1] + a.K[2]) >> 7);
     const int lds = red_bytes > stage_bytes ? red_bytes : stage_bytes;
+    if (lds > STREAM_LDS_MAX) return hipErrorInvalidValue;      // (mx_gemm_stream_grouped_supported keeps callers away from this)
     static DynamicLdsOnce once;
     if (lds > 65536) {
-        constexpr int MAX_RED = NW * (F * T16 >= 8 ? 1 : 3) * F * T16 * 1024, MAX_STAGE = NW * D * Ring<F, T16, W4>::SLOT;
-        hipError_t e = once.ensure(reinterpret_cast<const void *>(mx_gemm_stream_grouped_kernel<F, T16, D, NW, W4>), MAX_RED > MAX_STAGE ? MAX_RED : MAX_STAGE);
+        hipError_t e = once.ensure(reinterpret_cast<const void *>(mx_gemm_stream_grouped_kernel<F, T16, D, NW, W4>), STREAM_LDS_MAX);
         if (e != hipSuccess) return e;
     }
     const int blocks = (a.N + 16 * F - 1) / (16 * F);
@@ -750,11 +780,19 @@ extern "C" int mm_diag_set_stream_clock(void *buf) {
 
 // the grouped launch on the streaming kernel: every group M <= 64 (one to four token tiles); the workgroups of all groups count towards
 // filling the CUs
+// one token tile: the rings of the (F, D, NW) the dispatch may pick (at most 8 waves x 4 slots x (1 + 2) KB with fp4 weights, (2 + 2) KB
+// without) and both scale images (at most 8 waves, 16 rows per slab: the larger of the two geometries) must fit a workgroup's LDS
+static bool stream_images_fit(int M, const int K[3], bool w4) {
+    if (M > 16) return true;
+    const int T = (K[0] + K[1] + K[2]) >> 7;
+    const int rings = 8 * (T <= 32 ? 4 : 3) * (w4 ? 3 : 4) * 1024;
+    return rings + 2 * stream::scale_image_bytes(1, 8, T) <= stream::STREAM_LDS_MAX;
+}
 bool mx_gemm_stream_grouped_supported(int max_m, int ngroups, int N, const int K[3]) {
     static const int on = getenv("MICROMIX_STREAM_GROUPED") ? atoi(getenv("MICROMIX_STREAM_GROUPED")) : 1;   // kernel-developer override
-    (void)N; (void)K;
+    (void)N;
     static const int max_tokens = getenv("MICROMIX_STREAM_GROUPED_MAX_M") ? atoi(getenv("MICROMIX_STREAM_GROUPED_MAX_M")) : 64;
-    return on && max_m >= 1 && max_m <= max_tokens && max_m <= 64 && ngroups >= 1 && ngroups <= MM_MAX_GROUPS;
+    return on && max_m >= 1 && max_m <= max_tokens && max_m <= 64 && ngroups >= 1 && ngroups <= MM_MAX_GROUPS && stream_images_fit(max_m, K, false);
 }
 hipError_t launch_mx_gemm_stream_grouped(const GroupedGemmArgs &ga, int max_m, bool w4, hipStream_t stream) {
     using namespace stream;
@@ -770,12 +808,11 @@ hipError_t launch_mx_gemm_stream_grouped(const GroupedGemmArgs &ga, int max_m, b
 
 bool mx_gemm_stream_supported(int M, int N, const int K[3], bool w4) {
     static const int on = getenv("MICROMIX_STREAM") ? atoi(getenv("MICROMIX_STREAM")) : 1;   // kernel-developer override
-    (void)w4;
     if (!on || M > 64) return false;
     // few features, short K, a handful of tokens (q/k/v/o at M <= 8): the launch is all start-up, and the first kernel's is shorter
     // (q/o at M = 1: 4.65 against 5.0-5.5 us; from M = 16 on the two meet)
     if (M <= 8 && (N + 15) / 16 <= device_cus() && K[0] + K[1] + K[2] <= 8192) return false;
-    return true;
+    return stream_images_fit(M, K, w4);
 }
 
 // LDS that the ring / reduction tail of the quantizing launches may need beside the quantization's own range: the largest of the
