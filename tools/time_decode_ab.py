@@ -1,6 +1,6 @@
 """A/B of the fused decode launch (mm_qlinear_decode / mm_rmsnorm_qlinear_decode) across library variants, one process per variant
 (MICROMIX_HIP_LIB), interleaved passes: python tools/time_decode_ab.py lib_a.so lib_b.so ...  ("default" = the product library);
-AB_SHAPES=wide: the streaming kernel's layers; AB_PASSES=n"""
+AB_SHAPES=wide: the streaming kernel's layers; AB_PASSES=n; AB_HBM=1: weight copies in rotation (from HBM)"""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CHILD = r'''
@@ -34,6 +34,15 @@ for name, N, K, split in SHAPES:
         nw = torch.ones((K,), dtype=torch.bfloat16, device=dev)
         one = lambda: lib.mm_qlinear_decode(x.data_ptr(), idx.data_ptr(), *[pp(t) for t in b], M, N, *split, 1, 0, None, o.data_ptr(), st)
         one_n = lambda: lib.mm_rmsnorm_qlinear_decode(x.data_ptr(), nw.data_ptr(), 1e-5, idx.data_ptr(), *[pp(t) for t in b], M, N, *split, 1, 0, None, o.data_ptr(), st)
+        if os.environ.get("AB_HBM"):      # weights from HBM: copies in rotation, more than the 256 MB Infinity Cache holds
+            nb = sum(t.numel() for t in b)
+            cps = [[pp(t) for t in c] for c in [[t.clone() for t in b] for _ in range(max(2, int(600e6 // nb)))]]
+            it = [0]
+            def nxt():
+                it[0] = (it[0] + 1) %% len(cps)
+                return cps[it[0]]
+            one = lambda: lib.mm_qlinear_decode(x.data_ptr(), idx.data_ptr(), *nxt(), M, N, *split, 1, 0, None, o.data_ptr(), st)
+            one_n = lambda: lib.mm_rmsnorm_qlinear_decode(x.data_ptr(), nw.data_ptr(), 1e-5, idx.data_ptr(), *nxt(), M, N, *split, 1, 0, None, o.data_ptr(), st)
         assert one() == 0 and one_n() == 0
         out.append("%%-8s M=%%d plain %%5.2f norm %%5.2f" %% (name, M, timed(one), timed(one_n)))
 print(" | ".join(out))
