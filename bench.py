@@ -226,6 +226,9 @@ def llama_layer(dev, lib, mixedgemm, x, steps):
             o = mixedgemm.qlinear_decode(attn, idx, *L["o"], *in_split)
         else:
             o = mm(mixedgemm.reorder_quantize_x(attn, idx, *in_split), L["o"])
+        if mixedgemm.rmsnorm_gate_up_activate_decode_supported(m, I, *in_split) == 2:
+            # round 6: norm + quantize + gate | up GEMM + silu * up + the quantization for down_proj in ONE launch, down_proj a plain GEMM
+            return mm(mixedgemm.rmsnorm_gate_up_activate_decode(o, normw, 1e-5, idx, L["gu"], *down_split), L["down"])
         fused_gu = mixedgemm.rmsnorm_qlinear_decode_supported(m, 2 * I, *in_split) == 2
         if fused_gu and mixedgemm.down_activate_decode_supported(m, H, *down_split) == 2:
             gub = mixedgemm.rmsnorm_qlinear_decode(o, normw, 1e-5, idx, *L["gu"], *in_split)   # norm + quantize + gate | up GEMM in one launch ...
@@ -239,9 +242,12 @@ def llama_layer(dev, lib, mixedgemm, x, steps):
             return 7
         n = 1 if mixedgemm.rmsnorm_qlinear_decode_supported(m, H + 2 * NKV, *in_split) == 2 else 2
         n += 1 if mixedgemm.qlinear_decode_supported(m, H, *in_split) else 2
+        if mixedgemm.rmsnorm_gate_up_activate_decode_supported(m, I, *in_split) == 2:
+            return n + 2
         if mixedgemm.rmsnorm_qlinear_decode_supported(m, 2 * I, *in_split) == 2 and mixedgemm.down_activate_decode_supported(m, H, *down_split) == 2:
             return n + 2
-        return n + 4            # rmsnorm_quantize_x, gate | up GEMM, activation quantizer, down GEMM
+        one = "stream" in lib.mm_gate_up_activate_describe(m, I).decode()
+        return n + (3 if one else 4)            # rmsnorm_quantize_x, gate | up GEMM (+ activation quantizer: one launch on wide layers at M <= 16), down GEMM
 
     def measure(fn, xm, attn, reps):
         for _ in range(3):

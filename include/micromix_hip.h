@@ -198,6 +198,20 @@ int mm_gate_up_activate_decode(const void *X_bf16, const int16_t *reorder_index,
                                const uint8_t *SFBN, const uint8_t *SFBS, const uint8_t *SFBO, int M, int I, int KN, int KS, int KO, int DN,
                                int DS, int DO, int flags, uint8_t *oN, uint8_t *oS, uint8_t *oO, uint8_t *sfN, uint8_t *sfS, uint8_t *sfO,
                                void *workspace, size_t workspace_bytes, mm_stream_t stream);
+/* ... with the RMSNorm in front (post_attention_layernorm -> gate / up -> act_fn -> the quantization for down_proj; round 6, version >= 510):
+ * mm_rmsnorm_quantize -> mm_gate_up_activate, the same bytes.  On wide layers (2 I / 64 >= the CUs, K <= 8192) and M <= 4 it is ONE
+ * weight-streaming launch with the norm, the quantization of x, the GEMM, silu(gate) * up and the consumer's quantization inside
+ * (`workspace` unused); otherwise two launches (`workspace` as mm_gate_up_activate_decode).  Since round 6 mm_gate_up_activate (M <= 16)
+ * and mm_gate_up_activate_decode (M <= 4) run as one such launch too on layers that wide; down_proj is then a plain mm_matmul on o* / sf*.
+ * The _supported queries (also for mm_gate_up_activate_decode): 0 cannot run; 1 runs; 2 runs as ONE launch and is expected to be the
+ * fastest form of the MLP's first half (M <= 2; beyond that mm_rmsnorm_quantize / mm_reorder_quantize -> mm_gate_up_activate wins).
+ * flags: MM_ROUND_* | MM_NORM_NO_INTEGER_ROUND. */
+int mm_gate_up_activate_decode_supported(int M, int I, int KN, int KS, int KO);
+int mm_rmsnorm_gate_up_activate_decode_supported(int M, int I, int KN, int KS, int KO);
+int mm_rmsnorm_gate_up_activate_decode(const void *X_bf16, const void *norm_weight_bf16, float eps, const int16_t *reorder_index, const uint8_t *BN,
+                                       const uint8_t *BS, const uint8_t *BO, const uint8_t *SFBN, const uint8_t *SFBS, const uint8_t *SFBO, int M,
+                                       int I, int KN, int KS, int KO, int DN, int DS, int DO, int flags, uint8_t *oN, uint8_t *oS, uint8_t *oO,
+                                       uint8_t *sfN, uint8_t *sfS, uint8_t *sfO, void *workspace, size_t workspace_bytes, mm_stream_t stream);
 /* The other half of a decode-sized MLP: down_proj straight from the bf16 gate | up matrix GU [M, 2 I] (128 gate columns alternating with
  * the 128 up columns of the same indices: the layout mm_gate_up_activate's scratch and mm_qlinear_decode on an interleaved weight produce;
  * 16-byte aligned).  Every workgroup of the weight-streaming GEMM computes silu(gate) * up and quantizes it for its own use -- the

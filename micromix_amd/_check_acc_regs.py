@@ -66,7 +66,11 @@ def check_counted(asm_text):
 STREAM_OWN = re.compile(r"^\s*(v_mfma_scale_f32_16x16x128_f8f6f4|v_accvgpr_read_b32|v_accvgpr_write_b32)\b")
 STREAM_KERNEL = re.compile(r"^(_ZN2mm6stream\d+(mx_gemm_stream_kernel|mx_gemm_stream_grouped_kernel|mx_qlinear_stream_kernel|mx_qlinear_stream_rms_kernel)I((?:Li\d+E)+)Lb[01]E\w*):[^\n]*\n(.*?)\.end_amdhsa_kernel",
                            re.S | re.M)
-EXPECTED_STREAM_KERNELS = 60   # 20 plain + 16 grouped + 16 with the quantizer inside + 8 with norm and quantizer inside
+# ... and the three launches with the activation inside (stream_body ACT: F = 4, one token tile): mx_gemm_stream_act_kernel,
+# mx_qlinear_stream_act_kernel<RMS>
+STREAM_ACT_KERNEL = re.compile(r"^(_ZN2mm6stream\d+(mx_gemm_stream_act_kernel|mx_qlinear_stream_act_kernel)(?:ILb[01]EE|E)\w*):[^\n]*\n(.*?)\.end_amdhsa_kernel",
+                               re.S | re.M)
+EXPECTED_STREAM_KERNELS = 63   # 20 plain + 16 grouped + 16 with the quantizer inside + 8 with norm and quantizer inside + 3 with the activation inside
 VMEM = re.compile(r"^\s*(buffer_|global_|scratch_|flat_)(load|store|atomic)")
 
 
@@ -113,7 +117,7 @@ def pending_load_violations(body):
                 bad.append(code)
         if VMEM.match(code):
             dst = set()
-            if re.match(r"^\s*(buffer|global|scratch|flat)_load", code) and " lds" not in code and not code.rstrip().endswith("lds"):
+            if re.match(r"^\s*(buffer|global|scratch|flat)_load", code) and " lds" not in code and not code.rstrip().endswith("lds") and "_load_lds_" not in code:
                 first = code.split(None, 1)[1].split(",")[0]
                 dst = set(vgprs(first))
             pending.append(dst)
@@ -123,9 +127,9 @@ def pending_load_violations(body):
 def check_stream(asm_text):
     """(violations, kernels examined) for the assembly of mx_gemm_stream.hip"""
     bad, examined = [], []
-    for m in STREAM_KERNEL.finditer(asm_text):
-        sym, kind, ints, body = m.group(1), m.group(2), m.group(3), m.group(4)
-        n = stream_nacc(kind, ints)
+    found = [(m.group(1), stream_nacc(m.group(2), m.group(3)), m.group(4)) for m in STREAM_KERNEL.finditer(asm_text)]
+    found += [(m.group(1), 48, m.group(3)) for m in STREAM_ACT_KERNEL.finditer(asm_text)]
+    for sym, n, body in found:
         examined.append(sym)
         lines = [l.split(";")[0] for l in body.split("\n")]
         # The accumulators come to life at the kernel's first asm-owned instruction (acc_zero, placed BEHIND the quantization phase of the

@@ -18,7 +18,7 @@ EXPORTS = (
     "mm_sf_bytes_x", "mm_sf_bytes_w", "mm_sf_offset",
     "mm_reorder_quantize", "mm_reorder_quantize_gather", "mm_activate_quantize", "mm_downproj_quantize", "mm_matmul",
     "mm_matmul_ws", "mm_matmul_workspace_bytes", "mm_matmul_ws_reset",
-    "mm_gate_up_activate", "mm_gate_up_activate_decode", "mm_down_activate_decode", "mm_down_activate_decode_supported", "mm_down_activate_decode_supported_w", "mm_gate_up_activate_workspace_bytes", "mm_gate_up_activate_describe", "mm_rmsnorm_quantize", "mm_qlinear_decode", "mm_qlinear_decode_supported", "mm_qlinear_decode_supported_w", "mm_rmsnorm_qlinear_decode", "mm_rmsnorm_qlinear_decode_supported", "mm_rmsnorm_qlinear_decode_supported_w", "mm_matmul_grouped", "mm_reorder_quantize_grouped",
+    "mm_gate_up_activate", "mm_gate_up_activate_decode", "mm_rmsnorm_gate_up_activate_decode", "mm_rmsnorm_gate_up_activate_decode_supported", "mm_gate_up_activate_decode_supported", "mm_down_activate_decode", "mm_down_activate_decode_supported", "mm_down_activate_decode_supported_w", "mm_gate_up_activate_workspace_bytes", "mm_gate_up_activate_describe", "mm_rmsnorm_quantize", "mm_qlinear_decode", "mm_qlinear_decode_supported", "mm_qlinear_decode_supported_w", "mm_rmsnorm_qlinear_decode", "mm_rmsnorm_qlinear_decode_supported", "mm_rmsnorm_qlinear_decode_supported_w", "mm_matmul_grouped", "mm_reorder_quantize_grouped",
     "mm_matmul_describe", "mm_test_function", "mm_diag_set_kernel_events",
 )
 # every symbol include/micromix_diag.h declares (libmicromix_diag.so: hardware probes for tests/tools, never used by the ops)
@@ -105,6 +105,12 @@ def load():
     lib.mm_matmul_ws.argtypes = [vp] * 12 + [i] * 7 + [vp, vp, vp, ctypes.c_size_t, vp]
     lib.mm_gate_up_activate.restype = i
     lib.mm_gate_up_activate.argtypes = [vp] * 12 + [i] * 9 + [vp] * 7 + [ctypes.c_size_t, vp]
+    lib.mm_rmsnorm_gate_up_activate_decode_supported.restype = i
+    lib.mm_rmsnorm_gate_up_activate_decode_supported.argtypes = [i] * 5
+    lib.mm_gate_up_activate_decode_supported.restype = i
+    lib.mm_gate_up_activate_decode_supported.argtypes = [i] * 5
+    lib.mm_rmsnorm_gate_up_activate_decode.restype = i
+    lib.mm_rmsnorm_gate_up_activate_decode.argtypes = [vp, vp, ctypes.c_float] + [vp] * 7 + [i] * 9 + [vp] * 7 + [ctypes.c_size_t, vp]
     lib.mm_gate_up_activate_decode.restype = i
     lib.mm_gate_up_activate_decode.argtypes = [vp] * 8 + [i] * 9 + [vp] * 7 + [ctypes.c_size_t, vp]
     lib.mm_down_activate_decode_supported.restype = i

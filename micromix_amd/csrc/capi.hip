@@ -29,7 +29,7 @@ static bool split_ok(int K, int KN, int KS, int KO) {
 
 extern "C" {
 
-int mm_version(void) { return 500; /* 0.5.0: + the *_supported_w queries (weight mode); 0.4.0: + mm_rmsnorm_qlinear_decode(_supported) (0.3.0: + mm_gate_up_activate(_decode), mm_down_activate_decode, mm_matmul_ws_reset; 0.2.0: diagnostics moved to libmicromix_diag.so, + mm_test_function) */ }
+int mm_version(void) { return 510; /* 0.5.1: + mm_rmsnorm_gate_up_activate_decode(_supported), mm_gate_up_activate_decode_supported; mm_gate_up_activate(_decode) one launch at decode sizes; 0.5.0: + the *_supported_w queries (weight mode); 0.4.0: + mm_rmsnorm_qlinear_decode(_supported) (0.3.0: + mm_gate_up_activate(_decode), mm_down_activate_decode, mm_matmul_ws_reset; 0.2.0: diagnostics moved to libmicromix_diag.so, + mm_test_function) */ }
 
 const char *mm_test_function(void) { return "Hello from test_function!"; /* bindings.cpp:700 */ }
 
@@ -254,7 +254,29 @@ size_t mm_gate_up_activate_workspace_bytes(int M, int I) {
 
 const char *mm_gate_up_activate_describe(int M, int I) {
     if (M <= 0 || I <= 0 || (I % 128)) return "none";
+    const int Kany[3] = {0, 0, 4096};      // (the answer depends on K only for K in the tens of thousands: LDS of the scale images)
+    if (!mm::mx_gemm_act_supported(M, 2 * I) && mm::gate_up_act_stream_supported(M, 2 * I, Kany, false, false))
+        return "mm::stream::mx_gemm_stream_act_kernel (weight streaming with silu(gate) * up and the consumer's quantization inside, M <= 16)";
     return mm::describe_mx_gemm_act(M, 2 * I);
+}
+
+// the fused gate | up weight with the activation inside the weight-streaming launch (mx_gemm_stream.hip, ACT)
+static mm::GemmArgs act_stream_args(const uint8_t *BN, const uint8_t *BS, const uint8_t *BO, const uint8_t *SFBN, const uint8_t *SFBS, const uint8_t *SFBO,
+                                    int M, int I, int KN, int KS, int KO, int DN, int DS, int DO, int flags, uint8_t *oN, uint8_t *oS, uint8_t *oO,
+                                    uint8_t *sfN, uint8_t *sfS, uint8_t *sfO) {
+    mm::GemmArgs a = {};
+    a.W[0] = BN; a.W[1] = BS; a.W[2] = BO;
+    a.SFW[0] = SFBN; a.SFW[1] = SFBS; a.SFW[2] = SFBO;
+    a.K[0] = KN; a.K[1] = KS; a.K[2] = KO;
+    a.M = M; a.N = 2 * I;
+    a.sfx_row_tiles = 1;
+    a.sfw_row_tiles = (2 * I + 127) / 128;
+    a.round_per_segment = (flags & MM_ROUND_ONCE) ? 0 : 1;
+    a.act = 1;
+    a.act_K[0] = DN; a.act_K[1] = DS; a.act_K[2] = DO;
+    a.act_o[0] = oN; a.act_o[1] = oS; a.act_o[2] = oO;
+    a.act_sf[0] = sfN; a.act_sf[1] = sfS; a.act_sf[2] = sfO;
+    return a;
 }
 
 int mm_gate_up_activate(const uint8_t *AN, const uint8_t *BN, const uint8_t *AS, const uint8_t *BS, const uint8_t *AO,
@@ -271,6 +293,15 @@ int mm_gate_up_activate(const uint8_t *AN, const uint8_t *BN, const uint8_t *AS,
         return MM_ERR_BAD_ARG;
     if ((DN && (!oN || !sfN)) || (DS && (!oS || !sfS)) || (DO && (!oO || !sfO))) return MM_ERR_BAD_ARG;
     const int N = 2 * I;
+    const int Kin[3] = {KN, KS, KO};
+    if (!mm::mx_gemm_act_supported(M, N) && mm::gate_up_act_stream_supported(M, N, Kin, false, false)) {
+        // M <= 16 on a wide layer (round 6): ONE weight-streaming launch with the activation inside -- no scratch, the same bytes
+        mm::GemmArgs a = act_stream_args(BN, BS, BO, SFBN, SFBS, SFBO, M, I, KN, KS, KO, DN, DS, DO, flags, oN, oS, oO, sfN, sfS, sfO);
+        a.X[0] = AN; a.X[1] = AS; a.X[2] = AO;
+        a.SFX[0] = SFAN; a.SFX[1] = SFAS; a.SFX[2] = SFAO;
+        hipError_t e = mm::launch_gate_up_act_stream(a, (hipStream_t)stream);
+        return e == hipSuccess ? MM_OK : fail_hip(e, "mm_gate_up_activate");
+    }
     if (!mm::mx_gemm_act_supported(M, N)) {
         // M <= 64: the weight-streaming GEMM into the caller's scratch (columns alternate 128 gate | 128 up), then the activation
         // quantizer on that layout: the same bytes as the fused epilogue (tests/test_gate_up_gpu.py)
@@ -322,6 +353,15 @@ int mm_gate_up_activate_decode(const void *X_bf16, const int16_t *reorder_index,
     const int N = 2 * I;
     if (!mm_qlinear_decode_supported_w(M, N, KN, KS, KO, MM_W_FP4)) return MM_ERR_UNSUPPORTED;
     if ((DN && (!oN || !sfN)) || (DS && (!oS || !sfS)) || (DO && (!oO || !sfO))) return MM_ERR_BAD_ARG;
+    const int Kin[3] = {KN, KS, KO};
+    if (mm::gate_up_act_stream_supported(M, N, Kin, true, false)) {
+        // M <= 4 on a wide layer (round 6): quantization, GEMM, silu(gate) * up and the consumer's quantization in ONE launch
+        if (!X_bf16 || !reorder_index || ((uintptr_t)X_bf16 & 15)) return MM_ERR_BAD_ARG;
+        if ((KN && (!BN || !SFBN)) || (KS && (!BS || !SFBS)) || (KO && (!BO || !SFBO))) return MM_ERR_BAD_ARG;
+        const mm::GemmArgs a = act_stream_args(BN, BS, BO, SFBN, SFBS, SFBO, M, I, KN, KS, KO, DN, DS, DO, flags, oN, oS, oO, sfN, sfS, sfO);
+        hipError_t e = mm::launch_gate_up_act_stream_decode(X_bf16, reorder_index, a, (hipStream_t)stream);
+        return e == hipSuccess ? MM_OK : fail_hip(e, "mm_gate_up_activate_decode");
+    }
     if (!workspace || workspace_bytes < (size_t)M * N * sizeof(uint16_t) || ((uintptr_t)workspace & 15)) return MM_ERR_BAD_ARG;
     // quantize + gate | up GEMM in one launch into the scratch (columns alternate 128 gate | 128 up), then the activation quantizer on
     // that layout: the bytes of mm_reorder_quantize -> mm_gate_up_activate (tests/test_gate_up_gpu.py)
@@ -330,6 +370,53 @@ int mm_gate_up_activate_decode(const void *X_bf16, const int16_t *reorder_index,
     hipError_t e = mm::launch_direct_quantize(workspace, (const uint16_t *)workspace + 128, M, DN, DS, DO, 3, oN, oS, oO, sfN, sfS, sfO,
                                               (hipStream_t)stream);
     return e == hipSuccess ? MM_OK : fail_hip(e, "mm_gate_up_activate_decode");
+}
+
+// 2: ONE launch and expected to be the fastest way through the MLP's first half (M <= 2: at M = 3, 4 every workgroup repeating the
+// quantization loses to mm_rmsnorm_quantize / mm_reorder_quantize -> mm_gate_up_activate, itself one launch at M <= 16 --
+// tools/time_mlp_decode.py: Llama-3-8B MLP at M = 1 / 2 / 4 23.1 / 25.3 / 36.9 us against 26.3 / 26.7 / 27.2); 1: runs; 0: cannot
+int mm_rmsnorm_gate_up_activate_decode_supported(int M, int I, int KN, int KS, int KO) {
+    if (M < 1 || I < 128 || (I % 128) || KN < 0 || KS < 0 || KO < 0 || (KN % 128) || (KS % 128) || (KO % 128) || KN + KS + KO == 0) return 0;
+    const int Kin[3] = {KN, KS, KO};
+    if (mm::gate_up_act_stream_supported(M, 2 * I, Kin, true, true)) return M <= 2 ? 2 : 1;
+    return mm_rmsnorm_qlinear_decode_supported_w(M, 2 * I, KN, KS, KO, MM_W_FP4) ? 1 : 0;
+}
+int mm_gate_up_activate_decode_supported(int M, int I, int KN, int KS, int KO) {
+    if (M < 1 || I < 128 || (I % 128) || KN < 0 || KS < 0 || KO < 0 || (KN % 128) || (KS % 128) || (KO % 128) || KN + KS + KO == 0) return 0;
+    const int Kin[3] = {KN, KS, KO};
+    if (mm::gate_up_act_stream_supported(M, 2 * I, Kin, true, false)) return M <= 2 ? 2 : 1;
+    return mm_qlinear_decode_supported_w(M, 2 * I, KN, KS, KO, MM_W_FP4) ? 1 : 0;
+}
+
+int mm_rmsnorm_gate_up_activate_decode(const void *X_bf16, const void *norm_weight_bf16, float eps, const int16_t *reorder_index, const uint8_t *BN,
+                                       const uint8_t *BS, const uint8_t *BO, const uint8_t *SFBN, const uint8_t *SFBS, const uint8_t *SFBO, int M,
+                                       int I, int KN, int KS, int KO, int DN, int DS, int DO, int flags, uint8_t *oN, uint8_t *oS, uint8_t *oO,
+                                       uint8_t *sfN, uint8_t *sfS, uint8_t *sfO, void *workspace, size_t workspace_bytes, mm_stream_t stream) {
+    if (M < 0 || I < 0 || KN < 0 || KS < 0 || KO < 0) return MM_ERR_BAD_ARG;
+    if ((KN % 128) || (KS % 128) || (KO % 128) || KN + KS + KO == 0) return MM_ERR_BAD_SPLIT;
+    if (!split_ok(DN + DS + DO, DN, DS, DO) || DN + DS + DO != I) return MM_ERR_BAD_SPLIT;
+    if (flags & ~(MM_ROUND_ONCE | MM_NORM_NO_INTEGER_ROUND)) return MM_ERR_BAD_ARG;
+    if (M == 0) return MM_OK;
+    const int Kin[3] = {KN, KS, KO};
+    if (!mm_rmsnorm_gate_up_activate_decode_supported(M, I, KN, KS, KO)) return MM_ERR_UNSUPPORTED;
+    if (!X_bf16 || !norm_weight_bf16 || !reorder_index || ((uintptr_t)X_bf16 & 15) || ((uintptr_t)norm_weight_bf16 & 15)) return MM_ERR_BAD_ARG;
+    if ((KN && (!BN || !SFBN)) || (KS && (!BS || !SFBS)) || (KO && (!BO || !SFBO))) return MM_ERR_BAD_ARG;
+    if ((DN && (!oN || !sfN)) || (DS && (!oS || !sfS)) || (DO && (!oO || !sfO))) return MM_ERR_BAD_ARG;
+    if (mm::gate_up_act_stream_supported(M, 2 * I, Kin, true, true)) {
+        const mm::GemmArgs a = act_stream_args(BN, BS, BO, SFBN, SFBS, SFBO, M, I, KN, KS, KO, DN, DS, DO, flags, oN, oS, oO, sfN, sfS, sfO);
+        const mm::NormArgs norm = {norm_weight_bf16, eps, (flags & MM_NORM_NO_INTEGER_ROUND) ? 0 : 1};
+        hipError_t e = mm::launch_gate_up_act_stream_decode(X_bf16, reorder_index, a, (hipStream_t)stream, norm);
+        return e == hipSuccess ? MM_OK : fail_hip(e, "mm_rmsnorm_gate_up_activate_decode");
+    }
+    // two launches: norm + quantize + gate | up GEMM into the scratch, then the activation quantizer on it (the same bytes)
+    const int N = 2 * I;
+    if (!workspace || workspace_bytes < (size_t)M * N * sizeof(uint16_t) || ((uintptr_t)workspace & 15)) return MM_ERR_BAD_ARG;
+    const int st = mm_rmsnorm_qlinear_decode(X_bf16, norm_weight_bf16, eps, reorder_index, BN, BS, BO, SFBN, SFBS, SFBO, M, N, KN, KS, KO, MM_W_FP4,
+                                             flags, nullptr, workspace, stream);
+    if (st != MM_OK) return st;
+    hipError_t e = mm::launch_direct_quantize(workspace, (const uint16_t *)workspace + 128, M, DN, DS, DO, 3, oN, oS, oO, sfN, sfS, sfO,
+                                              (hipStream_t)stream);
+    return e == hipSuccess ? MM_OK : fail_hip(e, "mm_rmsnorm_gate_up_activate_decode");
 }
 
 int mm_down_activate_decode_supported_w(int M, int N, int DN, int DS, int DO, int wmode) {

@@ -221,7 +221,14 @@ __device__ __forceinline__ void m0_restore(unsigned keep) { MM_DEVICE_ONLY(asm v
 
 // slots per thread of dq::quantize_rows_early (see there): 2 on the four-wave kernels, whose register count costs no resident workgroup
 template <int NW> constexpr int EARLY_NPASS = NW <= 4 ? 2 : 1;
-template <int F, int T16, int D, int NW, bool W4, bool QUANT = false, bool RMS = false>
+// ACT (round 6; F = 4, one token tile, fp4 weights): the fused gate | up weight of mm_gate_up_activate -- 128 gate rows alternating with the
+// 128 up rows of the same indices -- with the activation INSIDE the launch.  Workgroup b takes the 32 gate rows 256 (b / 4) + 32 (b % 4) ..
+// and the 32 up rows 128 further on (its four 16-row tiles: gate, gate, up, up), i.e. both halves of ONE 32-column group of the
+// intermediate activation: after the reduction it computes h = silu(gate) * up on the bf16-rounded outputs (activate.cu:44-202, the
+// arithmetic of direct_quantize.hip), quantizes the group as mm_activate_quantize does and writes the consumer's (down_proj's) operand
+// bytes and scale byte -- a.act_o / a.act_sf / a.act_K -- instead of D.  The same bytes as GEMM -> mm_activate_quantize, one launch less,
+// and down_proj becomes a plain mm_matmul (M = 1: 7.3 us against 9.2 for mm_down_activate_decode).
+template <int F, int T16, int D, int NW, bool W4, bool QUANT = false, bool RMS = false, bool ACT = false>
 __device__ __forceinline__ void stream_body(const GemmArgs &a, const dq::QuantIn &qi = dq::QuantIn(), int qbytes = 0) {
     static_assert(T16 <= 4, "64 token rows: row groups 0 and 1 of the activation scale atoms, both in the 8 bytes a lane loads");
     static_assert(!QUANT || T16 == 1, "M <= 8");
@@ -231,12 +238,15 @@ __device__ __forceinline__ void stream_body(const GemmArgs &a, const dq::QuantIn
     using RG = Ring<F, T16, W4, QUANT>;
     static_assert((D - 1) * RG::LOADS < 64, "vmcnt is a 6-bit counter");
     constexpr int BN = 16 * F, ACC = F * T16, NT = 64 * NW;
-    const int n0 = blockIdx.x * BN;
+    static_assert(!ACT || (F == 4 && T16 == 1 && W4), "gate, gate, up, up");
+    // first weight row of the workgroup; tile f starts trow(f) rows further on
+    const int n0 = ACT ? 256 * ((int)blockIdx.x >> 2) + 32 * ((int)blockIdx.x & 3) : (int)blockIdx.x * BN;
+    auto trow = [](int f) { return ACT ? (f & 1) * 16 + (f >> 1) * 128 : 16 * f; };
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int li = lane & 15, h = lane >> 4, sh = 8 * h;
     const int ns[3] = {a.K[0] >> 7, a.K[1] >> 7, a.K[2] >> 7};
     const int c1 = ns[0], c2 = ns[0] + ns[1], T = c2 + ns[2];
-    const int wrows = a.N - n0 > BN ? BN : a.N - n0;
+    const int wrows = ACT ? 160 : (a.N - n0 > BN ? BN : a.N - n0);       // (ACT: N is a multiple of 256: rows n0 .. n0 + 159 exist)
     const bool half_tile = T16 == 1 && a.M <= 8;        // rows 0 .. 7 of a tile are in its first piece: the second is never requested (rows
                                                         // 8 .. 15 of the LDS image then hold stale bytes; their outputs are never stored)
     const unsigned ring = __builtin_amdgcn_readfirstlane(lds_address(smem) + wave * D * RG::SLOT);   // LDS byte address of slot 0
@@ -258,11 +268,11 @@ __device__ __forceinline__ void stream_body(const GemmArgs &a, const dq::QuantIn
     auto request_scales = [&]() {
       if constexpr (SIMG) {
         const unsigned keep_m0 = m0_save();
-        // one image: `rows16` 16-row tiles per slab starting at row `row0`, in 128-row scale tile `tile` (a segment's atoms: [tile][slab]); segment bases b0 .. b2
-        auto gather = [&](auto rows16_, const uint8_t *img, int row0, int tile, const uint8_t *b0, const uint8_t *b1, const uint8_t *b2) {
+        // one image: `rows16` 16-row tiles per slab, image row r = row row_of(r) of the tensor (a segment's atoms: [row >> 7][slab]); segment bases b0 .. b2
+        auto gather = [&](auto rows16_, const uint8_t *img, auto row_of, const uint8_t *b0, const uint8_t *b1, const uint8_t *b2) {
             constexpr int R = 16 * decltype(rows16_)::value, SPI = 64 / R;
             const unsigned img_lds = __builtin_amdgcn_readfirstlane(lds_address(img));
-            const int qd = lane / R, n = row0 + (lane % R);
+            const int qd = lane / R, n = row_of(lane % R), tile = n >> 7;
             const int aoff = (n & 31) * 16 + ((n >> 5) & 3) * 4;      // (atom row n & 31, row group (n >> 5) & 3): the dword of row n
             // (the three pointers as opaque scalars: hipcc otherwise turns the per-lane select between them into a per-lane LOAD from the
             // kernel-argument segment, with a wait for every outstanding load behind it, in every trip of the loop; the slab counts
@@ -283,10 +293,10 @@ __device__ __forceinline__ void stream_body(const GemmArgs &a, const dq::QuantIn
         };
         const int wimg = scale_image_wave_bytes(F, NW, T);
         const uint8_t *img = smem + NW * D * RG::SLOT;
-        gather(std::integral_constant<int, F>{}, img + wave * wimg, n0, n0 >> 7, a.SFW[0], a.SFW[1], a.SFW[2]);
+        gather(std::integral_constant<int, F>{}, img + wave * wimg, [&](int r) { return n0 + trow(r >> 4) + (r & 15); }, a.SFW[0], a.SFW[1], a.SFW[2]);
         if constexpr (!QUANT) {
             const int ximg = scale_image_wave_bytes(T16, NW, T);
-            gather(std::integral_constant<int, T16>{}, img + NW * wimg + wave * ximg, 0, 0, a.SFX[0], a.SFX[1], a.SFX[2]);
+            gather(std::integral_constant<int, T16>{}, img + NW * wimg + wave * ximg, [](int r) { return r; }, a.SFX[0], a.SFX[1], a.SFX[2]);
         }
         m0_restore(keep_m0);
       }
@@ -367,7 +377,7 @@ __device__ __forceinline__ void stream_body(const GemmArgs &a, const dq::QuantIn
             // only, so with it in soffset a lane whose row lies inside the descriptor's range would fetch rows past N (the
             // last workgroup when N is not a multiple of 16 F).  Unsigned: OOB + the term stays past every range and below 2^32.
             for (int f = 0; f < F; ++f) {
-                const int ft = 16 * f * wpitch[G];
+                const int ft = trow(f) * wpitch[G];
                 dma16(rw[G], (int)((unsigned)wva[G] + (unsigned)ft), s * WC * 16, base + f * RG::WP * 1024);
                 if constexpr (!W4) dma16(rw[G], (int)((unsigned)wvb[G] + (unsigned)ft), s * WC * 16, base + f * RG::WP * 1024 + 1024);
             }
@@ -597,6 +607,84 @@ __device__ __forceinline__ void stream_body(const GemmArgs &a, const dq::QuantIn
             // wave 0 instead of four passes over a 1024-entry image of which 64 are live (`reduce+store` 1.7 us of the fused gate + up launch,
             // tools/stream_clock.py).  The same sums in the same order: per segment the waves' partial sums in wave order, then the chain.
             const int rows = a.M < 16 ? a.M : 16, nlive = ACC * 16 * rows;
+            if constexpr (ACT) {
+                // thread (token m, column c of the workgroup's 32-column group): gate = tile c >> 4, up = tile 2 + (c >> 4), same lane and
+                // register; h = silu(bf16(gate)) * bf16(up) in fp32 (silu_mul, mx_direct_convert.h), quantized as direct_quantize.hip does
+                const int gi = blockIdx.x;          // the workgroup's group of the intermediate activation (wave-uniform segment)
+                const int gN = a.act_K[0] >> 5, gS = a.act_K[1] >> 5;
+                const int seg = gi < gN ? 0 : (gi < gN + gS ? 1 : 2);
+                // (QUANT: the group buffer in the staged rows' range, dead since the quantization phase -- 2 KB behind the reduction image
+                // would cost M = 2 its second workgroup per CU)
+                float *hbuf = QUANT ? reinterpret_cast<float *>(smem_all) : red + (size_t)NW * P * IMG;
+                for (int t = threadIdx.x; t < 32 * rows; t += NT) {
+                    const int m = t >> 5, c = t & 31, col = c & 15;
+                    const int og = (c >> 4) * 256 + (m & 3) * 64 + 16 * (m >> 2) + col, ou = og + 512;
+                    float rg = 0.0f, ru = 0.0f;
+                    for (int sl = 0; sl < P; ++sl) {
+                        float sg = 0.0f, su = 0.0f;
+#pragma unroll
+                        for (int w = 0; w < NW; ++w) {
+                            sg += red[((size_t)w * P + sl) * IMG + og];
+                            su += red[((size_t)w * P + sl) * IMG + ou];
+                        }
+                        sg += rg;
+                        su += ru;
+                        rg = a.round_per_segment ? bf16_bits_to_f32(f32_to_bf16_bits(sg)) : sg;
+                        ru = a.round_per_segment ? bf16_bits_to_f32(f32_to_bf16_bits(su)) : su;
+                    }
+                    const float hv = silu_mul(bf16_bits_to_f32(f32_to_bf16_bits(rg)), bf16_bits_to_f32(f32_to_bf16_bits(ru)));
+                    if (seg == 1) {
+                        hbuf[t] = hv;      // fp6: the converter wants the 32 values in one lane (below)
+                    } else {
+                        // fp4 / fp8: the 32 lanes of the token quantize their group together -- quantize32's arithmetic (mx_direct_convert.h):
+                        // the absmax through four DPP steps inside the rows of 16 lanes and one swap across them, the scale in every lane,
+                        // the even lane of a pair converts both values and stores their byte (fp4) / two bytes (fp8)
+                        float am = fabsf(hv);
+                        auto dpp_max = [&](auto ctrl_) {
+                            constexpr int ctrl = decltype(ctrl_)::value;
+                            am = fmaxf(am, __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(am), ctrl, 0xF, 0xF, false)));
+                        };
+                        dpp_max(std::integral_constant<int, 0xB1>{});       // quad_perm [1, 0, 3, 2]
+                        dpp_max(std::integral_constant<int, 0x4E>{});       // quad_perm [2, 3, 0, 1]
+                        dpp_max(std::integral_constant<int, 0x141>{});      // row_half_mirror
+                        dpp_max(std::integral_constant<int, 0x140>{});      // row_mirror
+                        am = fmaxf(am, __uint_as_float((uint32_t)__builtin_amdgcn_ds_swizzle((int)__float_as_uint(am), 0x401F)));      // lane ^ 16
+                        const float other = __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(hv), 0xB1, 0xF, 0xF, false));
+                        int e = 0;
+                        if (seg == 0) {
+                            if (am > 1e-6f) e = scale_exponent_f32<EL_FP4>(am);
+                            const float scale = __uint_as_float((uint32_t)(127 + (e < -126 ? -126 : e)) << 23);
+                            if ((c & 1) == 0) {
+                                const uint32_t r = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(0u, hv, other, scale, 0);
+                                a.act_o[0][(size_t)m * (a.act_K[0] >> 1) + gi * 16 + (c >> 1)] = (uint8_t)r;
+                            }
+                            if (c == 0) a.act_sf[0][sf_offset(m, gi, a.act_K[0])] = (uint8_t)(e + 127);
+                        } else {
+                            if (am > 1e-6f) e = scale_exponent_f32<EL_FP8>(am);
+                            const float scale = __uint_as_float((uint32_t)(127 + (e < -126 ? -126 : e)) << 23);
+                            if ((c & 1) == 0) {
+                                ds2 r = {0, 0};
+                                r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(r, hv, other, scale, false);
+                                *reinterpret_cast<uint16_t *>(a.act_o[2] + (size_t)m * a.act_K[2] + (gi - gN - gS) * 32 + c) = (uint16_t)r[0];
+                            }
+                            if (c == 0) a.act_sf[2][sf_offset(m, gi - gN - gS, a.act_K[2])] = (uint8_t)(e + 127);
+                        }
+                    }
+                }
+                if (seg == 1) {      // (wave-uniform: every thread takes the barrier or none)
+                    __syncthreads();
+                    if ((int)threadIdx.x < rows) {
+                        const int m = threadIdx.x;
+                        float v[32];
+#pragma unroll
+                        for (int i = 0; i < 32; ++i) v[i] = hbuf[m * 32 + i];
+                        const uint32_t byte = quantize32<EL_FP6, true>(v, a.act_o[1] + (size_t)m * ((a.act_K[1] >> 2) * 3) + (gi - gN) * 24);
+                        a.act_sf[1][sf_offset(m, gi - gN, a.act_K[1])] = (uint8_t)byte;
+                    }
+                }
+                MM_STAMP(4);
+                return;
+            }
             for (int t = threadIdx.x; t < nlive; t += NT) {
                 const int f = t / (16 * rows), rem = t - f * 16 * rows, m = rem >> 4, col = rem & 15;
                 const int o = f * 256 + (m & 3) * 64 + 16 * (m >> 2) + col;      // register m & 3 of lane 16 (m >> 2) + col of tile f
@@ -730,16 +818,28 @@ __global__ void __launch_bounds__(64 * NW) mx_qlinear_stream_rms_kernel(GemmArgs
     stream_body<F, 1, D, NW, W4, true, true>(a, qi, qbytes);
 }
 
-template <int F, int D, int NW, bool W4, bool RMS = false>
+// ... and with the activation inside (ACT, see stream_body): the fused gate | up weight, 64 rows (32 gate + 32 up) x 4 waves
+template <bool RMS>
+__global__ void __launch_bounds__(256) mx_qlinear_stream_act_kernel(GemmArgs a, dq::QuantIn qi, int qbytes) {
+    stream_body<4, 1, 2, 4, true, true, RMS, true>(a, qi, qbytes);
+}
+__global__ void __launch_bounds__(256) mx_gemm_stream_act_kernel(GemmArgs a) { stream_body<4, 1, 2, 4, true, false, false, true>(a); }
+constexpr int ACT_GROUP_BYTES = 16 * 32 * 4;       // the 32 values of a group for up to 16 tokens, behind the reduction image
+
+template <int F, int D, int NW, bool W4, bool RMS = false, bool ACT = false>
 static hipError_t launch_quant(const GemmArgs &a, dq::QuantIn qi, hipStream_t stream) {
-    if constexpr (!RMS && ((F == 4 && D == 2 && NW == 4) || (F == 2 && D == 2 && NW == 8) || (F == 1 && NW == 8 && (D == 3 || D == 4)))) {
+    static_assert(!ACT || (F == 4 && D == 2 && NW == 4 && W4), "mx_qlinear_stream_act_kernel");
+    if constexpr (ACT && !RMS) {
+        if (qi.norm_w != nullptr) return launch_quant<F, D, NW, W4, true, true>(a, qi, stream);
+    }
+    if constexpr (!ACT && !RMS && ((F == 4 && D == 2 && NW == 4) || (F == 2 && D == 2 && NW == 8) || (F == 1 && NW == 8 && (D == 3 || D == 4)))) {
         if (qi.norm_w != nullptr) return launch_quant<F, D, NW, W4, true>(a, qi, stream);      // (the configurations the default dispatch uses)
     }
     if (!RMS && qi.norm_w != nullptr) return hipErrorInvalidValue;       // (a kernel-developer override picked a configuration without a norm variant)
     const int present = (a.K[0] ? 1 : 0) + (a.K[1] ? 1 : 0) + (a.K[2] ? 1 : 0);
     const size_t Kt = (size_t)a.K[0] + a.K[1] + a.K[2];
     // [rings | scale image] while the slabs stream, then the reduction image over both
-    const size_t red_bytes = (size_t)NW * present * F * 4 * 64 * sizeof(float);
+    const size_t red_bytes = (size_t)NW * present * F * 4 * 64 * sizeof(float);      // (ACT: the group buffer lies in the staged rows' range)
     const size_t ring_bytes = (size_t)NW * D * Ring<F, 1, W4, true>::SLOT + scale_image_bytes(F, NW, (int)(Kt >> 7));
     const size_t tail = red_bytes > ring_bytes ? red_bytes : ring_bytes;
     const size_t ops = ((dq::operand_bytes(a.M, a.K) + 15) & ~(size_t)15) + (qi.norm_w != nullptr ? ((dq::rms_bytes(a.M, a.K) + 15) & ~(size_t)15) : 0);
@@ -761,7 +861,11 @@ static hipError_t launch_quant(const GemmArgs &a, dq::QuantIn qi, hipStream_t st
     const size_t qbytes = rows * Kt * 2 + ops, lds = qbytes + tail;
     if (lds > LDS_WG) return hipErrorInvalidValue;      // (every mode: the supported() predicates keep callers away from this)
     static DynamicLdsOnce once;
-    auto kern = [] { if constexpr (RMS) return mx_qlinear_stream_rms_kernel<F, D, NW, W4>; else return mx_qlinear_stream_kernel<F, D, NW, W4>; }();
+    auto kern = [] {
+        if constexpr (ACT) return mx_qlinear_stream_act_kernel<RMS>;
+        else if constexpr (RMS) return mx_qlinear_stream_rms_kernel<F, D, NW, W4>;
+        else return mx_qlinear_stream_kernel<F, D, NW, W4>;
+    }();
     if (lds > 65536) {
         hipError_t e = once.ensure(reinterpret_cast<const void *>(kern), (int)LDS_WG);
         if (e != hipSuccess) return e;
@@ -887,6 +991,47 @@ hipError_t launch_qlinear_stream(const void *X, const int16_t *idx, const uint8_
     if (wide) return w4 ? launch_quant<2, 2, 8, true>(a, qi, stream) : launch_quant<2, 2, 8, false>(a, qi, stream);
     if (((K[0] + K[1] + K[2]) >> 7) <= 32) return w4 ? launch_quant<1, 4, 8, true>(a, qi, stream) : launch_quant<1, 4, 8, false>(a, qi, stream);
     return w4 ? launch_quant<1, 3, 8, true>(a, qi, stream) : launch_quant<1, 3, 8, false>(a, qi, stream);
+}
+
+// The fused gate | up launch with the activation inside (stream_body ACT): N = 2 I rows of weights, 128 gate | 128 up alternating
+bool gate_up_act_stream_supported(int M, int N, const int K[3], bool from_bf16, bool rms) {
+    static const int on = getenv("MICROMIX_GATE_UP_ACT_STREAM") ? atoi(getenv("MICROMIX_GATE_UP_ACT_STREAM")) : 1;   // kernel-developer override
+    if (!on || M < 1 || N < 256 || (N % 256) != 0) return false;
+    if ((N + 63) / 64 < device_cus()) return false;          // 64-row workgroups: at least one per CU, else the two-launch form
+    const size_t Kt = (size_t)K[0] + K[1] + K[2];
+    if (!from_bf16) return M <= 16 && stream_images_fit(M, K, true);
+    if (M > 4 || (rms && Kt > (size_t)dq::RMS_MAX_K)) return false;
+    const size_t norm = rms ? ((dq::rms_bytes(M, K) + 15) & ~(size_t)15) : 0;
+    const size_t tail = 48 * 1024;      // (three segments' reduction image; the rings + scale image stay below; the group buffer lies in the staged row's range)
+    return Kt * 2 >= (size_t)stream::ACT_GROUP_BYTES && dq::operand_bytes(M, K) + 16 + norm + Kt * 2 + tail + 64 <= 156 * 1024 &&
+           stream::scale_image_bytes(4, 4, (int)(Kt >> 7)) <= 16 * 1024;
+}
+hipError_t launch_gate_up_act_stream(const GemmArgs &a, hipStream_t stream) {
+    using namespace stream;
+    const int present = (a.K[0] ? 1 : 0) + (a.K[1] ? 1 : 0) + (a.K[2] ? 1 : 0);
+    const int red_bytes = 4 * present * 4 * 4 * 64 * (int)sizeof(float) + ACT_GROUP_BYTES;
+    const int stage_bytes = 4 * 2 * Ring<4, 1, true>::SLOT + scale_images_bytes(4, 1, 4, (a.K[0] + a.K[1] + a.K[2]) >> 7);
+    const int lds = red_bytes > stage_bytes ? red_bytes : stage_bytes;
+    if (lds > STREAM_LDS_MAX) return hipErrorInvalidValue;
+    static DynamicLdsOnce once;
+    if (lds > 65536) {
+        hipError_t e = once.ensure(reinterpret_cast<const void *>(mx_gemm_stream_act_kernel), STREAM_LDS_MAX);
+        if (e != hipSuccess) return e;
+    }
+    MM_LAUNCH(mx_gemm_stream_act_kernel, dim3(a.N / 64), dim3(256), lds, stream, a);
+    return hipGetLastError();
+}
+hipError_t launch_gate_up_act_stream_decode(const void *X, const int16_t *idx, const GemmArgs &a, hipStream_t stream, const NormArgs &norm) {
+    using namespace stream;
+    dq::QuantIn qi = {};
+    qi.X = (const uint16_t *)X;
+    qi.idx = idx;
+    qi.M = a.M;
+    qi.norm_w = (const uint16_t *)norm.weight;
+    qi.eps = norm.eps;
+    qi.int_round = norm.int_round;
+    for (int g = 0; g < 3; ++g) qi.K[g] = a.K[g];
+    return launch_quant<4, 2, 4, true, false, true>(a, qi, stream);
 }
 
 // mm_down_activate_decode: down_proj at M <= 4 straight from the bf16 gate | up matrix -- every workgroup computes silu(gate) * up and

@@ -169,6 +169,11 @@ bool qlinear_stream_supported(int M, int N, const int K[3], bool rms = false, bo
 hipError_t launch_qlinear_stream(const void *X, const int16_t *idx, const uint8_t *const W[3], const uint8_t *const SFW[3], int M, int N,
                                  const int K[3], bool w4, int round_per_segment, const void *bias, void *D, hipStream_t stream,
                                  const NormArgs &norm = NO_NORM);
+// ... the fused gate | up weight (fp4) with silu(gate) * up and the quantization for the consumer inside the launch (a.act_K / act_o / act_sf;
+// round 6): from the quantized activations (M <= 16) or, `X` / `idx` / `norm`, from the bf16 rows (M <= 4)
+bool gate_up_act_stream_supported(int M, int N, const int K[3], bool from_bf16, bool rms);
+hipError_t launch_gate_up_act_stream(const GemmArgs &a, hipStream_t stream);
+hipError_t launch_gate_up_act_stream_decode(const void *X, const int16_t *idx, const GemmArgs &a, hipStream_t stream, const NormArgs &norm = NO_NORM);
 hipError_t launch_mx_gemm_skinny_grouped(const GroupedGemmArgs &ga, int max_m, bool w4, hipStream_t stream);
 size_t mx_gemm_workspace_bytes(int M, int N, const int K[3], bool w4, bool force, bool tickets_zeroed);
 bool mx_gemm_small_m_uses_tiles(int M, int N, const int K[3], bool w4, size_t ws_bytes, bool force_split);

@@ -522,6 +522,66 @@ def gate_up_activate_decode(X, reorder_index, B, DN, DS, DO, *, rounding="refere
     return oN, oS, oO, sfN, sfS, sfO
 
 
+def rmsnorm_gate_up_activate_decode_supported(M, I, KN, KS, KO):
+    """0: cannot run; 1: runs; 2: ONE launch with everything inside and expected to be the fastest form of the MLP's first half (M <= 2 on
+    a wide layer; mm_rmsnorm_gate_up_activate_decode_supported)"""
+    return int(_lib.load().mm_rmsnorm_gate_up_activate_decode_supported(int(M), int(I), int(KN), int(KS), int(KO)))
+
+
+def gate_up_activate_decode_supported(M, I, KN, KS, KO):
+    """the same for `gate_up_activate_decode` (no norm)"""
+    return int(_lib.load().mm_gate_up_activate_decode_supported(int(M), int(I), int(KN), int(KS), int(KO)))
+
+
+def rmsnorm_gate_up_activate_decode(X, norm_weight, eps, reorder_index, B, DN, DS, DO, *, rounding="reference", integer_round=True):
+    """`gate_up_activate(rmsnorm_quantize_x(X, norm_weight, eps, reorder_index, KN, KS, KO), B, DN, DS, DO)` for decode-sized batches: the
+    post-attention RMSNorm, the quantization of x, the gate | up GEMM on the interleaved weight B, silu(gate) * up and the quantization for
+    down_proj -- ONE launch on a wide layer at M <= 4, two otherwise (`rmsnorm_gate_up_activate_decode_supported(...) == 2`: where it is the
+    fastest form).  Returns
+    down_proj's activation operands (oN, oS, oO, sfN, sfS, sfO): `matmul` them with the packed down_proj weight.  Same bytes as the
+    three-op form.  Not an export of the reference module."""
+    lib = _lib.load()
+    dev = X.device
+    index = dev.index
+    if not (X.is_cuda and _ok(X, torch.bfloat16, index) and _ok(reorder_index, torch.int16, index) and _ok(norm_weight, torch.bfloat16, index)):
+        _check_tensor(X, "X", torch.bfloat16)
+        _check_tensor(norm_weight, "norm_weight", torch.bfloat16, dev)
+        _check_tensor(reorder_index, "reorder_index", torch.int16, dev)
+    for t in B:
+        if not _ok(t, torch.uint8, index):
+            _check_tensor(t, "operand", torch.uint8, dev)
+    M, K = X.shape
+    N2 = B[0].size(0)
+    KN, KS, KO = B[0].size(1) * 2, B[1].size(1) * 2, B[2].size(1) * 2
+    I = N2 // 2
+    DN, DS, DO = int(DN), int(DS), int(DO)
+    if N2 % 256 or K != KN + KS + KO or reorder_index.numel() != K or norm_weight.numel() != K or B[1].size(0) != N2 or B[2].size(0) != N2:
+        raise RuntimeError("B must be an interleaved fp4 gate/up weight (interleave_gate_up) whose split adds up to X's columns")
+    if DN < 0 or DS < 0 or DO < 0 or DN % 128 or DS % 128 or DO % 128 or DN + DS + DO != I:
+        _lib.check(_lib.MM_ERR_BAD_SPLIT, "activate_quantize_x")
+    for n, t, need in (("SFBN", B[3], _sf_bytes_w(N2, KN)), ("SFBS", B[4], _sf_bytes_w(N2, KS)), ("SFBO", B[5], _sf_bytes_w(N2, KO))):
+        if t.numel() < need:
+            raise RuntimeError(f"{n} holds {t.numel()} scale bytes, needs at least {need}")
+    if rounding not in ("reference", "fused"):
+        raise ValueError("rounding must be 'reference' or 'fused'")
+    flags = (_lib.MM_ROUND_PER_SEGMENT if rounding == "reference" else _lib.MM_ROUND_ONCE) | (0 if integer_round else _lib.MM_NORM_NO_INTEGER_ROUND)
+    u8 = torch.uint8
+    oN = torch.empty((M, DN // 2), dtype=u8, device=dev)
+    oS = torch.empty((M, DS // 4 * 3), dtype=u8, device=dev)
+    oO = torch.empty((M, DO), dtype=u8, device=dev)
+    sfN = torch.empty((_sf_bytes_x(M, DN),), dtype=u8, device=dev)
+    sfS = torch.empty((_sf_bytes_x(M, DS),), dtype=u8, device=dev)
+    sfO = torch.empty((_sf_bytes_x(M, DO),), dtype=u8, device=dev)
+    ws = torch.empty((M * N2 * 2,), dtype=u8, device=dev)      # (scratch of the two-launch form; stream-ordered, from the caching allocator)
+    with _on_device(index):
+        st = lib.mm_rmsnorm_gate_up_activate_decode(_ptr(X), _ptr(norm_weight), float(eps), _ptr(reorder_index), _ptr(B[0]), _ptr(B[1]), _ptr(B[2]),
+                                                    _ptr(B[3]), _ptr(B[4]), _ptr(B[5]), M, I, KN, KS, KO, DN, DS, DO, flags, _ptr(oN), _ptr(oS),
+                                                    _ptr(oO), _ptr(sfN), _ptr(sfS), _ptr(sfO), _ptr(ws), ws.numel(), _stream_ptr(dev))
+    if st:
+        _lib.check(st, "rmsnorm_gate_up_activate_decode")
+    return oN, oS, oO, sfN, sfS, sfO
+
+
 def down_activate_decode_supported(M, N, DN, DS, DO, weight_mode="w4"):
     """0: cannot run; 1: runs; 2: runs and is expected to beat activate_quantize_x + matmul (mm_down_activate_decode_supported_w)"""
     return int(_lib.load().mm_down_activate_decode_supported_w(int(M), int(N), int(DN), int(DS), int(DO), _wmode_of(weight_mode)))

@@ -339,8 +339,17 @@ class FusedMLP(nn.Module):
         gu = (self.GU_BN, self.GU_BS, self.GU_BO, self.GU_SFBN, self.GU_SFBS, self.GU_SFBO)
         m = x2.size(0)
         down = (self.D_BN, self.D_BS, self.D_BO, self.D_SFBN, self.D_SFBS, self.D_SFBO)
+        # (a wide layer: gate_up_activate is ONE launch at M <= 16 -- then the fused pairs below, whose workgroups all repeat the
+        # quantization, only win at M <= 2)
+        pair_rows = 2 if mixedgemm.gate_up_activate_decode_supported(1, self.inter, *self.in_split) == 2 else 4
         if norm_weight is not None:
-            if m <= 4 and mixedgemm.rmsnorm_qlinear_decode_supported(m, 2 * self.inter, *self.in_split) == 2 \
+            if m <= 2 and mixedgemm.rmsnorm_gate_up_activate_decode_supported(m, self.inter, *self.in_split) == 2:
+                # round 6: norm, quantization, gate | up GEMM, silu * up and the quantization for down_proj in ONE launch; down_proj a plain GEMM
+                qh = mixedgemm.rmsnorm_gate_up_activate_decode(x2, norm_weight, eps, self.reorder_index, gu, *self.down_split, rounding=self.rounding)
+                y = mixedgemm.matmul(qh[0], self.D_BN, qh[1], self.D_BS, qh[2], self.D_BO, qh[3], self.D_SFBN, qh[4], self.D_SFBS, qh[5],
+                                     self.D_SFBO, rounding=self.rounding)
+                return y.reshape(*lead, self.hidden)
+            if m <= pair_rows and mixedgemm.rmsnorm_qlinear_decode_supported(m, 2 * self.inter, *self.in_split) == 2 \
                     and mixedgemm.down_activate_decode_supported(m, self.hidden, *self.down_split) == 2:
                 gub = mixedgemm.rmsnorm_qlinear_decode(x2, norm_weight, eps, self.reorder_index, *gu, *self.in_split, rounding=self.rounding)
                 return mixedgemm.down_activate_decode(gub, down, *self.down_split, rounding=self.rounding).reshape(*lead, self.hidden)
@@ -349,13 +358,18 @@ class FusedMLP(nn.Module):
             y = mixedgemm.matmul(qh[0], self.D_BN, qh[1], self.D_BS, qh[2], self.D_BO, qh[3], self.D_SFBN, qh[4], self.D_SFBS, qh[5],
                                  self.D_SFBO, rounding=self.rounding)
             return y.reshape(*lead, self.hidden)
-        if m <= 4 and mixedgemm.qlinear_decode_supported(m, 2 * self.inter, *self.in_split) == 2 \
+        if m <= 2 and mixedgemm.gate_up_activate_decode_supported(m, self.inter, *self.in_split) == 2:
+            qh = mixedgemm.gate_up_activate_decode(x2, self.reorder_index, gu, *self.down_split, rounding=self.rounding)      # ONE launch (round 6)
+            y = mixedgemm.matmul(qh[0], self.D_BN, qh[1], self.D_BS, qh[2], self.D_BO, qh[3], self.D_SFBN, qh[4], self.D_SFBS, qh[5],
+                                 self.D_SFBO, rounding=self.rounding)
+            return y.reshape(*lead, self.hidden)
+        if m <= pair_rows and mixedgemm.qlinear_decode_supported(m, 2 * self.inter, *self.in_split) == 2 \
                 and mixedgemm.down_activate_decode_supported(m, self.hidden, *self.down_split) == 2:
             # decode, TWO launches: reorder + quantize + the gate | up GEMM, then down_proj with silu * up + its quantization inside
             # every workgroup (the same bytes as the five-launch form)
             gub = mixedgemm.qlinear_decode(x2, self.reorder_index, *gu, *self.in_split, rounding=self.rounding)
             return mixedgemm.down_activate_decode(gub, down, *self.down_split, rounding=self.rounding).reshape(*lead, self.hidden)
-        if m <= 8 and mixedgemm.qlinear_decode_supported(m, 2 * self.inter, *self.in_split) == 2:
+        if pair_rows == 4 and m <= 8 and mixedgemm.qlinear_decode_supported(m, 2 * self.inter, *self.in_split) == 2:
             # decode: reorder + quantize + the gate | up GEMM in one launch, then the activation quantizer (same bytes, one launch fewer)
             qh = mixedgemm.gate_up_activate_decode(x2, self.reorder_index, gu, *self.down_split, rounding=self.rounding)
         else:

@@ -100,6 +100,48 @@ def test_decode_form_equals_quantize_then_fused(dev, m, h, i, in_split, dsplit):
         mixedgemm.gate_up_activate_decode(torch.cat([x] * 9)[:9].contiguous(), idx, qgu, *dsplit)      # M = 9: not a decode batch
 
 
+# Round 6: on wide layers (2 I / 64 >= the CUs) the decode-sized forms run as ONE weight-streaming launch with the activation inside
+# (mx_gemm_stream.hip, ACT).  Held byte for byte to the three-op twin -- matmul(gate), matmul(up) -> activate_quantize_x, which shares
+# no code with that epilogue -- from the quantized activations (M <= 16), from the bf16 rows (M <= 4) and with the RMSNorm in front.
+ONE_LAUNCH = [(1, 1024, 8192, (512, 128, 384), (4096, 2048, 2048)), (3, 1024, 8192, (0, 0, 1024), (0, 8192, 0)), (4, 512, 8448, (512, 0, 0), (8448, 0, 0)),
+              (1, 4096, 14336, (2048, 128, 1920), (12288, 1024, 1024)), (2, 4096, 14336, (2048, 128, 1920), (7168, 512, 6656))]
+
+
+@pytest.mark.parametrize("m,h,i,in_split,dsplit", ONE_LAUNCH, ids=[f"{c[0]}x{c[1]}x{c[2]}" for c in ONE_LAUNCH])
+def test_one_launch_forms_equal_three_ops(dev, m, h, i, in_split, dsplit):
+    import torch
+    rng = np.random.default_rng(m * 13 + h + i)
+    x = t_from_bits(make_inputs(rng, m, h), dev)
+    wg = t_from_bits(make_inputs(rng, i, h, "weight"), dev) * 8
+    wu = t_from_bits(make_inputs(rng, i, h, "weight"), dev) * 8
+    nw = t_from_bits(o.f32_to_bf16((1.0 + 0.2 * rng.standard_normal(h)).astype(np.float32)), dev)
+    idx = torch.from_numpy(rng.permutation(h).astype(np.int16)).to(dev)
+    qg = mixedgemm.reorder_quantize_w4(wg, idx, *in_split)
+    qu = mixedgemm.reorder_quantize_w4(wu, idx, *in_split)
+    qgu = mixedgemm.interleave_gate_up(qg, qu)
+    cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    wide = 2 * i // 64 >= cus
+    assert mixedgemm.rmsnorm_gate_up_activate_decode_supported(m, i, *in_split) == (2 if wide and m <= 2 else 1)
+    assert mixedgemm.gate_up_activate_decode_supported(m, i, *in_split) == (2 if wide and m <= 2 else 1)
+    qx = mixedgemm.reorder_quantize_x(x, idx, *in_split)
+    qn = mixedgemm.rmsnorm_quantize_x(x, nw, 1e-5, idx, *in_split)
+    for rounding in ("reference", "fused"):
+        want = three_op(qx, qg, qu, dsplit, rounding)
+        assert_same_operands(mixedgemm.gate_up_activate(qx, qgu, *dsplit, rounding=rounding), want, m, dsplit, f"quantized x {rounding}")
+        assert_same_operands(mixedgemm.gate_up_activate_decode(x, idx, qgu, *dsplit, rounding=rounding), want, m, dsplit, f"bf16 x {rounding}")
+        want_n = three_op(qn, qg, qu, dsplit, rounding)
+        got_n = mixedgemm.rmsnorm_gate_up_activate_decode(x, nw, 1e-5, idx, qgu, *dsplit, rounding=rounding)
+        assert_same_operands(got_n, want_n, m, dsplit, f"norm {rounding}")
+    # M = 16 from the quantized activations (the widest batch of the one-launch form)
+    x16 = t_from_bits(make_inputs(rng, 16, h), dev)
+    q16 = mixedgemm.reorder_quantize_x(x16, idx, *in_split)
+    assert_same_operands(mixedgemm.gate_up_activate(q16, qgu, *dsplit), three_op(q16, qg, qu, dsplit), 16, dsplit, "quantized x M=16")
+    # and the MLP's second half on those operands is a plain matmul
+    wd = t_from_bits(make_inputs(rng, 256, i, "weight"), dev)
+    b = mixedgemm.downproj_quantize_w4(wd, *dsplit)
+    assert torch.equal(_mm(got_n, b), _mm(want_n, b))
+
+
 # down_proj straight from the bf16 gate | up matrix (mm_down_activate_decode, M <= 4): bit-identical to activate_quantize_x -> matmul;
 # every consumer format, N with a ragged last workgroup, two passes of the in-workgroup quantizer (M * I / 32 > 512), bias, both weight
 # modes, both roundings; Llama's own shapes

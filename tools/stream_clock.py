@@ -26,7 +26,20 @@ for name, N, K, split in (("q/o", 4096, 4096, (2048, 128, 1920)), ("gate/up", 14
     out = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
     ptrs = [pp(t) for t in (a[0], b[0], a[1], b[1], a[2], b[2], a[3], b[3], a[4], b[4], a[5], b[5])]
     f = lambda: lib.mm_matmul(*ptrs, M, N, *split, 1, 0, None, out.data_ptr(), st)
-    if MODE == "down":       # mm_down_activate_decode: silu(gate) * up, quantized inside every workgroup (K = the intermediate size)
+    if MODE == "act":        # mm_rmsnorm_gate_up_activate_decode: norm + quantize + gate | up GEMM + silu * up + the quantization for down_proj
+        if name != "gate+up":
+            continue
+        I = N // 2
+        dsp = (12288, 1024, 1024)
+        nw = torch.ones((K,), dtype=torch.bfloat16, device=dev)
+        outs = [torch.empty((M, dsp[0] // 2), dtype=torch.uint8, device=dev), torch.empty((M, dsp[1] // 4 * 3), dtype=torch.uint8, device=dev),
+                torch.empty((M, dsp[2]), dtype=torch.uint8, device=dev)] + [torch.empty((128 * d // 32,), dtype=torch.uint8, device=dev) for d in dsp]
+        bp = [pp(t) for t in b]
+        f = lambda: lib.mm_rmsnorm_gate_up_activate_decode(x.data_ptr(), nw.data_ptr(), 1e-5, idx.data_ptr(), *bp, M, I, *split, *dsp, 0,
+                                                           *[t.data_ptr() for t in outs], None, 0, st)
+        if f() != 0:
+            print(f"{name:8s} M={M}: {MODE} not supported"); continue
+    elif MODE == "down":       # mm_down_activate_decode: silu(gate) * up, quantized inside every workgroup (K = the intermediate size)
         if name != "down":
             continue
         gu = torch.randn((M, 2 * K), generator=g).to(torch.bfloat16).to(dev)
