@@ -70,7 +70,7 @@ STREAM_KERNEL = re.compile(r"^(_ZN2mm6stream\d+(mx_gemm_stream_kernel|mx_gemm_st
 # mx_qlinear_stream_act_kernel<RMS>
 STREAM_ACT_KERNEL = re.compile(r"^(_ZN2mm6stream\d+(mx_gemm_stream_act_kernel|mx_qlinear_stream_act_kernel)(?:ILb[01]EE|E)\w*):[^\n]*\n(.*?)\.end_amdhsa_kernel",
                                re.S | re.M)
-EXPECTED_STREAM_KERNELS = 63   # 20 plain + 16 grouped + 16 with the quantizer inside + 8 with norm and quantizer inside + 3 with the activation inside
+EXPECTED_STREAM_KERNELS = 67   # 22 plain + 18 grouped + 16 with the quantizer inside + 8 with norm and quantizer inside + 3 with the activation inside
 VMEM = re.compile(r"^\s*(buffer_|global_|scratch_|flat_)(load|store|atomic)")
 
 

@@ -69,6 +69,9 @@ typedef int rsrc_t __attribute__((ext_vector_type(4)));
 #endif
 
 
+// launches without the quantization that take their scales from scale images (see stream_body): one token tile, and two with fp4 weights
+__host__ __device__ constexpr bool scale_images_for(int T16, bool W4) { return T16 == 1 || (T16 == 2 && W4); }
+
 // 128-bit raw buffer descriptor {base_lo, base_hi(16 bits) | stride 0, num_records (bytes), flags}, every word provably
 // wave-uniform so that it can be bound to an "s" operand
 __device__ __forceinline__ rsrc_t make_rsrc(const uint8_t *base, unsigned bytes) {
@@ -171,7 +174,7 @@ struct Ring {
     // vector-memory instructions of a slab, at least: the second piece of an activation tile is requested only where it holds rows the
     // launch has (fp4 tiles are one piece; M <= 8: rows 0 .. 7 sit in the first piece of every format).  The counted waits use this
     // minimum -- with longer slabs behind it a wait lets at most one instruction fewer stay in flight, never one too many.
-    static constexpr int LOADS = ((MM_STREAM_DBG & 16) ? 0 : F * WP) + ((MM_STREAM_DBG & 1) || QUANT ? 0 : T16) + ((MM_STREAM_DBG & 2) || QUANT || T16 == 1 ? 0 : 2);
+    static constexpr int LOADS = ((MM_STREAM_DBG & 16) ? 0 : F * WP) + ((MM_STREAM_DBG & 1) || QUANT ? 0 : T16) + ((MM_STREAM_DBG & 2) || QUANT || scale_images_for(T16, W4) ? 0 : 2);
 };
 
 // chunks per row of a segment's 128-deep slab: fp4 4, fp6 6, fp8 8 (x 16 bytes)
@@ -203,8 +206,8 @@ __host__ __device__ constexpr int scale_image_wave_bytes(int F, int NW, int T) {
 }
 __host__ __device__ constexpr int scale_image_bytes(int F, int NW, int T) { return NW * scale_image_wave_bytes(F, NW, T); }
 // both images of a launch without the quantization (weights' rows 16 F, activations' 16 T16): one token tile only, see stream_body
-__host__ __device__ constexpr int scale_images_bytes(int F, int T16, int NW, int T) {
-    return T16 == 1 ? scale_image_bytes(F, NW, T) + scale_image_bytes(T16, NW, T) : 0;
+__host__ __device__ constexpr int scale_images_bytes(int F, int T16, int NW, int T, bool W4) {
+    return scale_images_for(T16, W4) ? scale_image_bytes(F, NW, T) + scale_image_bytes(T16, NW, T) : 0;
 }
 constexpr int STREAM_LDS_MAX = 160 * 1024;      // (the 64-token configuration on 16 features uses all of a CU's LDS)
 // one global_load_lds_dword: lane l's dword at `p` -> LDS byte lds + 4 l (M0 = lds; counted by vmcnt like the ring's DMA)
@@ -263,7 +266,7 @@ __device__ __forceinline__ void stream_body(const GemmArgs &a, const dq::QuantIn
     // wave's rows but possibly in front of a later wave's by 0.8-1.3 (tools/stream_clock.py).  So: once the wave's own rows have landed
     // (the early reorder phase's `landed` hook; fused gate + up at M = 1 12.8 -> 12.0 us against in front), in front for the other phases
     // (below); the loop starts with one wait for everything requested under the phase.  Not QUANT: in front of the ring's first slabs.
-    constexpr bool SIMG = (QUANT || T16 == 1) && !(MM_STREAM_DBG & 2);
+    constexpr bool SIMG = (QUANT || scale_images_for(T16, W4)) && !(MM_STREAM_DBG & 2);
     [[maybe_unused]] const uint8_t *simg = nullptr, *simgx = nullptr;       // + 64 F i + 64 f (+ 64 i): the scale byte of (slab i, this lane's row and K block) -- see consume_g
     auto request_scales = [&]() {
       if constexpr (SIMG) {
@@ -417,7 +420,7 @@ __device__ __forceinline__ void stream_body(const GemmArgs &a, const dq::QuantIn
 #pragma unroll
         for (int f = 0; f < F; ++f) {
             if constexpr (SIMG) sw[f] = (int)simg[i * (64 * F) + 64 * f];      // (dword 16 F i + 16 f + li of the image, byte h)
-            else if constexpr (QUANT || T16 == 1) sw[f] = 0;                   // (MM_STREAM_DBG & 2)
+            else if constexpr (QUANT || scale_images_for(T16, W4)) sw[f] = 0;   // (MM_STREAM_DBG & 2)
             else sw[f] = __builtin_amdgcn_ds_bpermute(sfw_src[f], sfw_hi[f] ? q.sw[1] : q.sw[0]) >> sh;
         }
         typename Frag<G>::type xv[T16];
@@ -438,7 +441,7 @@ __device__ __forceinline__ void stream_body(const GemmArgs &a, const dq::QuantIn
 #pragma unroll
             for (int t = 0; t < T16; ++t) {
                 if constexpr (SIMG) sx[t] = (int)simgx[i * (64 * T16) + 64 * t];
-                else if constexpr (T16 == 1) sx[t] = 0;                        // (MM_STREAM_DBG & 2)
+                else if constexpr (scale_images_for(T16, W4)) sx[t] = 0;        // (MM_STREAM_DBG & 2)
                 else sx[t] = __builtin_amdgcn_ds_bpermute(sfx_src[t], t >= 2 ? q.sx[1] : q.sx[0]) >> sh;
             }
 #pragma unroll
@@ -764,7 +767,7 @@ static hipError_t launch_one(const GemmArgs &a, hipStream_t stream) {
     const int present = (a.K[0] ? 1 : 0) + (a.K[1] ? 1 : 0) + (a.K[2] ? 1 : 0);
     // [rings | scale images] while the slabs stream, then the reduction image over both
     const int red_bytes = NW * (F * T16 >= 8 ? 1 : present) * F * T16 * 4 * 64 * (int)sizeof(float);
-    const int stage_bytes = NW * D * Ring<F, T16, W4>::SLOT + scale_images_bytes(F, T16, NW, (a.K[0] + a.K[1] + a.K[2]) >> 7);
+    const int stage_bytes = NW * D * Ring<F, T16, W4>::SLOT + scale_images_bytes(F, T16, NW, (a.K[0] + a.K[1] + a.K[2]) >> 7, W4);
     const int lds = red_bytes > stage_bytes ? red_bytes : stage_bytes;
     if (lds > STREAM_LDS_MAX) return hipErrorInvalidValue;      // (mx_gemm_stream_supported keeps callers away from this)
     static DynamicLdsOnce once;
@@ -790,7 +793,7 @@ static hipError_t launch_grouped_one(const GroupedGemmArgs &ga, hipStream_t stre
     const GemmArgs &a = ga.g[0];
     const int present = (a.K[0] ? 1 : 0) + (a.K[1] ? 1 : 0) + (a.K[2] ? 1 : 0);
     const int red_bytes = NW * (F * T16 >= 8 ? 1 : present) * F * T16 * 4 * 64 * (int)sizeof(float);
-    const int stage_bytes = NW * D * Ring<F, T16, W4>::SLOT + scale_images_bytes(F, T16, NW, (a.K[0] + a.K[1] + a.K[2]) >> 7);
+    const int stage_bytes = NW * D * Ring<F, T16, W4>::SLOT + scale_images_bytes(F, T16, NW, (a.K[0] + a.K[1] + a.K[2]) >> 7, W4);
     const int lds = red_bytes > stage_bytes ? red_bytes : stage_bytes;
     if (lds > STREAM_LDS_MAX) return hipErrorInvalidValue;      // (mx_gemm_stream_grouped_supported keeps callers away from this)
     static DynamicLdsOnce once;
@@ -887,9 +890,14 @@ extern "C" int mm_diag_set_stream_clock(void *buf) {
 // filling the CUs
 // one token tile: the rings of the (F, D, NW) the dispatch may pick (at most 8 waves x 4 slots x (1 + 2) KB with fp4 weights, (2 + 2) KB
 // without) and both scale images (at most 8 waves, 16 rows per slab: the larger of the two geometries) must fit a workgroup's LDS
+// 16 features x two token tiles x 8 waves with fp4 weights: `depth` slots of 1 + 4 KB and both images
+static bool two_tile_fits(int depth, int T) {
+    return 8 * depth * 5 * 1024 + stream::scale_image_bytes(1, 8, T) + stream::scale_image_bytes(2, 8, T) <= stream::STREAM_LDS_MAX;
+}
 static bool stream_images_fit(int M, const int K[3], bool w4) {
-    if (M > 16) return true;
+    if (M > 32 || (M > 16 && !w4)) return true;
     const int T = (K[0] + K[1] + K[2]) >> 7;
+    if (M > 16) return two_tile_fits(2, T);      // (the 32-feature configuration: 4 waves x 2 slots x 6 KB + smaller images)
     const int rings = 8 * (T <= 32 ? 4 : 3) * (w4 ? 3 : 4) * 1024;
     return rings + 2 * stream::scale_image_bytes(1, 8, T) <= stream::STREAM_LDS_MAX;
 }
@@ -897,7 +905,7 @@ bool mx_gemm_stream_grouped_supported(int max_m, int ngroups, int N, const int K
     static const int on = getenv("MICROMIX_STREAM_GROUPED") ? atoi(getenv("MICROMIX_STREAM_GROUPED")) : 1;   // kernel-developer override
     (void)N;
     static const int max_tokens = getenv("MICROMIX_STREAM_GROUPED_MAX_M") ? atoi(getenv("MICROMIX_STREAM_GROUPED_MAX_M")) : 64;
-    return on && max_m >= 1 && max_m <= max_tokens && max_m <= 64 && ngroups >= 1 && ngroups <= MM_MAX_GROUPS && stream_images_fit(max_m, K, false);
+    return on && max_m >= 1 && max_m <= max_tokens && max_m <= 64 && ngroups >= 1 && ngroups <= MM_MAX_GROUPS && stream_images_fit(max_m, K, false) && stream_images_fit(max_m, K, true);      // (either weight mode)
 }
 hipError_t launch_mx_gemm_stream_grouped(const GroupedGemmArgs &ga, int max_m, bool w4, hipStream_t stream) {
     using namespace stream;
@@ -905,6 +913,11 @@ hipError_t launch_mx_gemm_stream_grouped(const GroupedGemmArgs &ga, int max_m, b
 #define MM_STREAM_G(F_, T_, D_, NW_)                                                 \
     (w4 ? launch_grouped_one<F_, T_, D_, NW_, true>(ga, stream) : launch_grouped_one<F_, T_, D_, NW_, false>(ga, stream))
     if (max_m <= 16) return wide ? MM_STREAM_G(2, 1, 2, 8) : MM_STREAM_G(1, 1, 3, 8);
+    if (max_m <= 32 && w4) {      // (as launch_mx_gemm_stream: scale images with two token tiles)
+        const int slabs = (ga.g[0].K[0] + ga.g[0].K[1] + ga.g[0].K[2]) >> 7;
+        if (wide) return launch_grouped_one<2, 2, 2, 4, true>(ga, stream);
+        return two_tile_fits(3, slabs) ? launch_grouped_one<1, 2, 3, 8, true>(ga, stream) : launch_grouped_one<1, 2, 2, 8, true>(ga, stream);
+    }
     if (max_m <= 32) return wide ? MM_STREAM_G(2, 2, 3, 4) : MM_STREAM_G(1, 2, 3, 8);
     if (max_m <= 48) return wide ? MM_STREAM_G(2, 3, 2, 4) : MM_STREAM_G(1, 3, 2, 8);
     return wide ? MM_STREAM_G(2, 4, 2, 4) : MM_STREAM_G(1, 4, 2, 8);
@@ -1010,7 +1023,7 @@ hipError_t launch_gate_up_act_stream(const GemmArgs &a, hipStream_t stream) {
     using namespace stream;
     const int present = (a.K[0] ? 1 : 0) + (a.K[1] ? 1 : 0) + (a.K[2] ? 1 : 0);
     const int red_bytes = 4 * present * 4 * 4 * 64 * (int)sizeof(float) + ACT_GROUP_BYTES;
-    const int stage_bytes = 4 * 2 * Ring<4, 1, true>::SLOT + scale_images_bytes(4, 1, 4, (a.K[0] + a.K[1] + a.K[2]) >> 7);
+    const int stage_bytes = 4 * 2 * Ring<4, 1, true>::SLOT + scale_images_bytes(4, 1, 4, (a.K[0] + a.K[1] + a.K[2]) >> 7, true);
     const int lds = red_bytes > stage_bytes ? red_bytes : stage_bytes;
     if (lds > STREAM_LDS_MAX) return hipErrorInvalidValue;
     static DynamicLdsOnce once;
@@ -1102,6 +1115,13 @@ hipError_t launch_mx_gemm_stream(const GemmArgs &a, bool w4, hipStream_t stream)
     const int slabs = (a.K[0] + a.K[1] + a.K[2]) >> 7;
     // (few features: four slots when a wave's slabs are at most four -- K <= 4096: everything is requested at once, no phantom steps)
     if (a.M <= 16) return wide ? MM_STREAM(2, 1, 2, 8) : (slabs <= 32 ? MM_STREAM(1, 1, 4, 8) : MM_STREAM(1, 1, 3, 8));
+    // 17 .. 32 tokens.  fp4 weights take their scales from images (round 6): on 32 features two slots instead of three keep the second
+    // workgroup's place in the LDS (gate/up 10.1-10.8 -> 9.4-9.8 us); on 16 features (one workgroup per CU) three slots while rings and
+    // images fit, else two (down_proj 12.0 -> 11.1)
+    if (a.M <= 32 && w4) {
+        if (wide) return launch_one<2, 2, 2, 4, true>(a, stream);
+        return two_tile_fits(3, slabs) ? launch_one<1, 2, 3, 8, true>(a, stream) : launch_one<1, 2, 2, 8, true>(a, stream);
+    }
     if (a.M <= 32) return wide ? MM_STREAM(2, 2, 3, 4) : MM_STREAM(1, 2, 3, 8);
     // 33 .. 64 tokens: three / four token tiles; two slots of 8 / 10 KB and four waves, so that two workgroups fit a CU's LDS
     if (a.M <= 48) return wide ? MM_STREAM(2, 3, 2, 4) : MM_STREAM(1, 3, 2, 8);
