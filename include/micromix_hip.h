@@ -201,7 +201,7 @@ int mm_gate_up_activate_decode(const void *X_bf16, const int16_t *reorder_index,
 /* ... with the RMSNorm in front (post_attention_layernorm -> gate / up -> act_fn -> the quantization for down_proj; round 6, version >= 510):
  * mm_rmsnorm_quantize -> mm_gate_up_activate, the same bytes.  On wide layers (2 I / 64 >= the CUs, K <= 8192) and M <= 4 it is ONE
  * weight-streaming launch with the norm, the quantization of x, the GEMM, silu(gate) * up and the consumer's quantization inside
- * (`workspace` unused); otherwise two launches (`workspace` as mm_gate_up_activate_decode).  Since round 6 mm_gate_up_activate (M <= 16)
+ * (`workspace` unused); otherwise two launches (`workspace` as mm_gate_up_activate_decode).  Since round 6 mm_gate_up_activate (M <= 32)
  * and mm_gate_up_activate_decode (M <= 4) run as one such launch too on layers that wide; down_proj is then a plain mm_matmul on o* / sf*.
  * The _supported queries (also for mm_gate_up_activate_decode): 0 cannot run; 1 runs; 2 runs as ONE launch and is expected to be the
  * fastest form of the MLP's first half (M <= 2; beyond that mm_rmsnorm_quantize / mm_reorder_quantize -> mm_gate_up_activate wins).

@@ -66,11 +66,11 @@ def check_counted(asm_text):
 STREAM_OWN = re.compile(r"^\s*(v_mfma_scale_f32_16x16x128_f8f6f4|v_accvgpr_read_b32|v_accvgpr_write_b32)\b")
 STREAM_KERNEL = re.compile(r"^(_ZN2mm6stream\d+(mx_gemm_stream_kernel|mx_gemm_stream_grouped_kernel|mx_qlinear_stream_kernel|mx_qlinear_stream_rms_kernel)I((?:Li\d+E)+)Lb[01]E\w*):[^\n]*\n(.*?)\.end_amdhsa_kernel",
                            re.S | re.M)
-# ... and the three launches with the activation inside (stream_body ACT: F = 4, one token tile): mx_gemm_stream_act_kernel,
+# ... and the launches with the activation inside (stream_body ACT: F = 4): mx_gemm_stream_act_kernel<T16 = 1, 2>,
 # mx_qlinear_stream_act_kernel<RMS>
-STREAM_ACT_KERNEL = re.compile(r"^(_ZN2mm6stream\d+(mx_gemm_stream_act_kernel|mx_qlinear_stream_act_kernel)(?:ILb[01]EE|E)\w*):[^\n]*\n(.*?)\.end_amdhsa_kernel",
+STREAM_ACT_KERNEL = re.compile(r"^(_ZN2mm6stream\d+(mx_gemm_stream_act_kernel|mx_qlinear_stream_act_kernel)I(?:Lb[01]|Li(\d+))EE\w*):[^\n]*\n(.*?)\.end_amdhsa_kernel",
                                re.S | re.M)
-EXPECTED_STREAM_KERNELS = 67   # 22 plain + 18 grouped + 16 with the quantizer inside + 8 with norm and quantizer inside + 3 with the activation inside
+EXPECTED_STREAM_KERNELS = 68   # 22 plain + 18 grouped + 16 with the quantizer inside + 8 with norm and quantizer inside + 4 with the activation inside
 VMEM = re.compile(r"^\s*(buffer_|global_|scratch_|flat_)(load|store|atomic)")
 
 
@@ -128,7 +128,7 @@ def check_stream(asm_text):
     """(violations, kernels examined) for the assembly of mx_gemm_stream.hip"""
     bad, examined = [], []
     found = [(m.group(1), stream_nacc(m.group(2), m.group(3)), m.group(4)) for m in STREAM_KERNEL.finditer(asm_text)]
-    found += [(m.group(1), 48, m.group(3)) for m in STREAM_ACT_KERNEL.finditer(asm_text)]
+    found += [(m.group(1), 48 * int(m.group(3) or 1), m.group(4)) for m in STREAM_ACT_KERNEL.finditer(asm_text)]      # <T16> / <RMS>: 12 * 4 * T16
     for sym, n, body in found:
         examined.append(sym)
         lines = [l.split(";")[0] for l in body.split("\n")]

@@ -256,7 +256,7 @@ const char *mm_gate_up_activate_describe(int M, int I) {
     if (M <= 0 || I <= 0 || (I % 128)) return "none";
     const int Kany[3] = {0, 0, 4096};      // (the answer depends on K only for K in the tens of thousands: LDS of the scale images)
     if (!mm::mx_gemm_act_supported(M, 2 * I) && mm::gate_up_act_stream_supported(M, 2 * I, Kany, false, false))
-        return "mm::stream::mx_gemm_stream_act_kernel (weight streaming with silu(gate) * up and the consumer's quantization inside, M <= 16)";
+        return "mm::stream::mx_gemm_stream_act_kernel (weight streaming with silu(gate) * up and the consumer's quantization inside, M <= 32)";
     return mm::describe_mx_gemm_act(M, 2 * I);
 }
 

@@ -241,7 +241,7 @@ __device__ __forceinline__ void stream_body(const GemmArgs &a, const dq::QuantIn
     using RG = Ring<F, T16, W4, QUANT>;
     static_assert((D - 1) * RG::LOADS < 64, "vmcnt is a 6-bit counter");
     constexpr int BN = 16 * F, ACC = F * T16, NT = 64 * NW;
-    static_assert(!ACT || (F == 4 && T16 == 1 && W4), "gate, gate, up, up");
+    static_assert(!ACT || (F == 4 && T16 <= 2 && W4 && (T16 == 1 || (NW == 4 && !QUANT))), "gate, gate, up, up");
     // first weight row of the workgroup; tile f starts trow(f) rows further on
     const int n0 = ACT ? 256 * ((int)blockIdx.x >> 2) + 32 * ((int)blockIdx.x & 3) : (int)blockIdx.x * BN;
     auto trow = [](int f) { return ACT ? (f & 1) * 16 + (f >> 1) * 128 : 16 * f; };
@@ -739,6 +739,76 @@ __device__ __forceinline__ void stream_body(const GemmArgs &a, const dq::QuantIn
             for (int k = 0; k < PER; ++k) chain(k, s[k]);
         }
     }
+    if constexpr (ACT && T16 > 1) {
+        // ACT with two token tiles (17 .. 32 tokens; the single-tile launches left through the live-output reduction above).  256 threads,
+        // 8 outputs each: o = thread + 256 k is (tile k = f T16 + t, register r = wave, lane l) -- so run[f T16 + t] (f = 0, 1: gate) and
+        // run[(f + 2) T16 + t] (up) of one thread belong to the same token 16 t + 4 (l >> 4) + r and to columns (l & 15) + 16 f of the
+        // workgroup's group, whose other columns sit in the other lanes of the DPP row: the group's absmax is four DPP steps, no LDS.
+        static_assert(NT == 256 && PER == 4 * T16, "tile = k");
+        const int l = threadIdx.x & 63, r = threadIdx.x >> 6, col = l & 15;
+        const int gi = blockIdx.x, gN = a.act_K[0] >> 5, gS = a.act_K[1] >> 5;
+        const int seg = gi < gN ? 0 : (gi < gN + gS ? 1 : 2);
+        float *hbuf = red;                      // (fp6 groups only, behind a barrier: the reduction image is done with)
+        if (seg == 1) __syncthreads();
+        static_for<T16>([&](auto t_) {
+            constexpr int t = decltype(t_)::value;
+            const int m = 16 * t + 4 * (l >> 4) + r;
+            const bool live = m < a.M;
+            auto bf = [](float x) { return bf16_bits_to_f32(f32_to_bf16_bits(x)); };
+            const float h0 = silu_mul(bf(run[t]), bf(run[2 * T16 + t])), h1 = silu_mul(bf(run[T16 + t]), bf(run[3 * T16 + t]));
+            if (seg == 1) {
+                if (live) { hbuf[m * 32 + col] = h0; hbuf[m * 32 + 16 + col] = h1; }
+            } else {
+                float am = fmaxf(fabsf(h0), fabsf(h1));
+                auto dpp_max = [&](auto ctrl_) {
+                    constexpr int ctrl = decltype(ctrl_)::value;
+                    am = fmaxf(am, __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(am), ctrl, 0xF, 0xF, false)));
+                };
+                dpp_max(std::integral_constant<int, 0xB1>{});       // quad_perm [1, 0, 3, 2]
+                dpp_max(std::integral_constant<int, 0x4E>{});       // quad_perm [2, 3, 0, 1]
+                dpp_max(std::integral_constant<int, 0x141>{});      // row_half_mirror
+                dpp_max(std::integral_constant<int, 0x140>{});      // row_mirror
+                const float o0 = __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(h0), 0xB1, 0xF, 0xF, false));
+                const float o1 = __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(h1), 0xB1, 0xF, 0xF, false));
+                int e = 0;
+                if (seg == 0) {
+                    if (am > 1e-6f) e = scale_exponent_f32<EL_FP4>(am);
+                    const float scale = __uint_as_float((uint32_t)(127 + (e < -126 ? -126 : e)) << 23);
+                    if (live && (col & 1) == 0) {
+                        uint8_t *out = a.act_o[0] + (size_t)m * (a.act_K[0] >> 1) + gi * 16 + (col >> 1);
+                        out[0] = (uint8_t)__builtin_amdgcn_cvt_scalef32_pk_fp4_f32(0u, h0, o0, scale, 0);
+                        out[8] = (uint8_t)__builtin_amdgcn_cvt_scalef32_pk_fp4_f32(0u, h1, o1, scale, 0);
+                    }
+                    if (live && col == 0) a.act_sf[0][sf_offset(m, gi, a.act_K[0])] = (uint8_t)(e + 127);
+                } else {
+                    if (am > 1e-6f) e = scale_exponent_f32<EL_FP8>(am);
+                    const float scale = __uint_as_float((uint32_t)(127 + (e < -126 ? -126 : e)) << 23);
+                    if (live && (col & 1) == 0) {
+                        uint8_t *out = a.act_o[2] + (size_t)m * a.act_K[2] + (gi - gN - gS) * 32 + col;
+                        ds2 q0 = {0, 0}, q1 = {0, 0};
+                        q0 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(q0, h0, o0, scale, false);
+                        q1 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(q1, h1, o1, scale, false);
+                        *reinterpret_cast<uint16_t *>(out) = (uint16_t)q0[0];
+                        *reinterpret_cast<uint16_t *>(out + 16) = (uint16_t)q1[0];
+                    }
+                    if (live && col == 0) a.act_sf[2][sf_offset(m, gi - gN - gS, a.act_K[2])] = (uint8_t)(e + 127);
+                }
+            }
+        });
+        if (seg == 1) {
+            __syncthreads();
+            if ((int)threadIdx.x < a.M) {
+                const int m = threadIdx.x;
+                float v[32];
+#pragma unroll
+                for (int i = 0; i < 32; ++i) v[i] = hbuf[m * 32 + i];
+                const uint32_t byte = quantize32<EL_FP6, true>(v, a.act_o[1] + (size_t)m * ((a.act_K[1] >> 2) * 3) + (gi - gN) * 24);
+                a.act_sf[1][sf_offset(m, gi - gN, a.act_K[1])] = (uint8_t)byte;
+            }
+        }
+        MM_STAMP(4);
+        return;
+    }
     // output o = (i = f * T16 + t, r, l): token 16 t + 4 (l >> 4) + r, feature n0 + 16 f + (l & 15)
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
@@ -826,7 +896,8 @@ template <bool RMS>
 __global__ void __launch_bounds__(256) mx_qlinear_stream_act_kernel(GemmArgs a, dq::QuantIn qi, int qbytes) {
     stream_body<4, 1, 2, 4, true, true, RMS, true>(a, qi, qbytes);
 }
-__global__ void __launch_bounds__(256) mx_gemm_stream_act_kernel(GemmArgs a) { stream_body<4, 1, 2, 4, true, false, false, true>(a); }
+template <int T16>
+__global__ void __launch_bounds__(256) mx_gemm_stream_act_kernel(GemmArgs a) { stream_body<4, T16, 2, 4, true, false, false, true>(a); }
 constexpr int ACT_GROUP_BYTES = 16 * 32 * 4;       // the 32 values of a group for up to 16 tokens, behind the reduction image
 
 template <int F, int D, int NW, bool W4, bool RMS = false, bool ACT = false>
@@ -1012,27 +1083,35 @@ bool gate_up_act_stream_supported(int M, int N, const int K[3], bool from_bf16, 
     if (!on || M < 1 || N < 256 || (N % 256) != 0) return false;
     if ((N + 63) / 64 < device_cus()) return false;          // 64-row workgroups: at least one per CU, else the two-launch form
     const size_t Kt = (size_t)K[0] + K[1] + K[2];
-    if (!from_bf16) return M <= 16 && stream_images_fit(M, K, true);
+    if (!from_bf16) {      // one or two token tiles: 4 waves x 2 slots x (4 + 2 T16) KB and both scale images
+        const int T16 = M <= 16 ? 1 : 2;
+        return M <= 32 && 4 * 2 * (4 + 2 * T16) * 1024 + stream::scale_images_bytes(4, T16, 4, (int)(Kt >> 7), true) <= stream::STREAM_LDS_MAX;
+    }
     if (M > 4 || (rms && Kt > (size_t)dq::RMS_MAX_K)) return false;
     const size_t norm = rms ? ((dq::rms_bytes(M, K) + 15) & ~(size_t)15) : 0;
     const size_t tail = 48 * 1024;      // (three segments' reduction image; the rings + scale image stay below; the group buffer lies in the staged row's range)
     return Kt * 2 >= (size_t)stream::ACT_GROUP_BYTES && dq::operand_bytes(M, K) + 16 + norm + Kt * 2 + tail + 64 <= 156 * 1024 &&
            stream::scale_image_bytes(4, 4, (int)(Kt >> 7)) <= 16 * 1024;
 }
-hipError_t launch_gate_up_act_stream(const GemmArgs &a, hipStream_t stream) {
+template <int T16>
+static hipError_t launch_gate_up_act_tiles(const GemmArgs &a, hipStream_t stream) {
     using namespace stream;
     const int present = (a.K[0] ? 1 : 0) + (a.K[1] ? 1 : 0) + (a.K[2] ? 1 : 0);
-    const int red_bytes = 4 * present * 4 * 4 * 64 * (int)sizeof(float) + ACT_GROUP_BYTES;
-    const int stage_bytes = 4 * 2 * Ring<4, 1, true>::SLOT + scale_images_bytes(4, 1, 4, (a.K[0] + a.K[1] + a.K[2]) >> 7, true);
+    // (two token tiles: eight tiles per wave reduce one segment at a time through one image; the fp6 group buffer lies inside it)
+    const int red_bytes = 4 * (4 * T16 >= 8 ? 1 : present) * 4 * T16 * 4 * 64 * (int)sizeof(float) + (T16 == 1 ? ACT_GROUP_BYTES : 0);
+    const int stage_bytes = 4 * 2 * Ring<4, T16, true>::SLOT + scale_images_bytes(4, T16, 4, (a.K[0] + a.K[1] + a.K[2]) >> 7, true);
     const int lds = red_bytes > stage_bytes ? red_bytes : stage_bytes;
     if (lds > STREAM_LDS_MAX) return hipErrorInvalidValue;
     static DynamicLdsOnce once;
     if (lds > 65536) {
-        hipError_t e = once.ensure(reinterpret_cast<const void *>(mx_gemm_stream_act_kernel), STREAM_LDS_MAX);
+        hipError_t e = once.ensure(reinterpret_cast<const void *>(mx_gemm_stream_act_kernel<T16>), STREAM_LDS_MAX);
         if (e != hipSuccess) return e;
     }
-    MM_LAUNCH(mx_gemm_stream_act_kernel, dim3(a.N / 64), dim3(256), lds, stream, a);
+    MM_LAUNCH(mx_gemm_stream_act_kernel<T16>, dim3(a.N / 64), dim3(256), lds, stream, a);
     return hipGetLastError();
+}
+hipError_t launch_gate_up_act_stream(const GemmArgs &a, hipStream_t stream) {
+    return a.M <= 16 ? launch_gate_up_act_tiles<1>(a, stream) : launch_gate_up_act_tiles<2>(a, stream);
 }
 hipError_t launch_gate_up_act_stream_decode(const void *X, const int16_t *idx, const GemmArgs &a, hipStream_t stream, const NormArgs &norm) {
     using namespace stream;

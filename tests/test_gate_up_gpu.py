@@ -132,10 +132,15 @@ def test_one_launch_forms_equal_three_ops(dev, m, h, i, in_split, dsplit):
         want_n = three_op(qn, qg, qu, dsplit, rounding)
         got_n = mixedgemm.rmsnorm_gate_up_activate_decode(x, nw, 1e-5, idx, qgu, *dsplit, rounding=rounding)
         assert_same_operands(got_n, want_n, m, dsplit, f"norm {rounding}")
-    # M = 16 from the quantized activations (the widest batch of the one-launch form)
-    x16 = t_from_bits(make_inputs(rng, 16, h), dev)
-    q16 = mixedgemm.reorder_quantize_x(x16, idx, *in_split)
-    assert_same_operands(mixedgemm.gate_up_activate(q16, qgu, *dsplit), three_op(q16, qg, qu, dsplit), 16, dsplit, "quantized x M=16")
+    # M = 16 (the widest single-tile batch) and two token tiles (17 .. 32 tokens) from the quantized activations
+    for mm_ in (16, 17, 27, 32):
+        xq = t_from_bits(make_inputs(rng, mm_, h), dev)
+        qq = mixedgemm.reorder_quantize_x(xq, idx, *in_split)
+        for rounding in ("reference", "fused"):
+            assert_same_operands(mixedgemm.gate_up_activate(qq, qgu, *dsplit, rounding=rounding), three_op(qq, qg, qu, dsplit, rounding), mm_, dsplit,
+                                 f"quantized x M={mm_} {rounding}")
+        if wide:
+            assert "stream_act" in _lib.load().mm_gate_up_activate_describe(mm_, i).decode()
     # and the MLP's second half on those operands is a plain matmul
     wd = t_from_bits(make_inputs(rng, 256, i, "weight"), dev)
     b = mixedgemm.downproj_quantize_w4(wd, *dsplit)

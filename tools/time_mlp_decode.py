@@ -12,7 +12,7 @@ g = torch.Generator(device=dev).manual_seed(3)
 H, I = 4096, 14336
 in_split, down_split = (2048, 128, 1920), (12288, 1024, 1024)
 rnd = lambda r, c: (torch.randn((r, c), generator=g, device=dev) * 0.02).to(torch.bfloat16)
-x8 = torch.randn((8, H), generator=g, device=dev).to(torch.bfloat16)
+x8 = torch.randn((32, H), generator=g, device=dev).to(torch.bfloat16)
 idx = torch.argsort(x8.float().abs().mean(0)).to(torch.int16)
 nw = torch.ones((H,), dtype=torch.bfloat16, device=dev)
 gu = mixedgemm.interleave_gate_up(mixedgemm.reorder_quantize_w4(rnd(I, H), idx, *in_split), mixedgemm.reorder_quantize_w4(rnd(I, H), idx, *in_split))
@@ -35,7 +35,7 @@ def graph_time(fn, reps=20):
         torch.cuda.synchronize()
         best = min(best, (time.perf_counter() - t0) / (10 * reps))
     return best * 1e6
-for m in (1, 2, 3, 4, 8):
+for m in (1, 2, 3, 4, 8, 16, 24, 32):
     x = x8[:m].contiguous()
     A = lambda: mixedgemm.down_activate_decode(mixedgemm.rmsnorm_qlinear_decode(x, nw, 1e-5, idx, *gu, *in_split), wd, *down_split)
     B = lambda: mm(mixedgemm.rmsnorm_gate_up_activate_decode(x, nw, 1e-5, idx, gu, *down_split), wd)
