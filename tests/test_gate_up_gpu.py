@@ -269,3 +269,42 @@ def test_errors(dev):
     assert out[0].shape == (128, 128) and out[2].shape == (128, 0)
     assert int(u8(out[0]).max()) == 0                                   # silu(0) * 0 = 0 -> fp4 code 0
     assert int(u8(out[3])[o.sf_valid_offsets(128, 256)].min()) == 127  # empty block: scale 1.0 (activate.cu:117-120), not 0.5
+
+
+def test_norm_decode_form_errors_and_fallback(dev):
+    """mm_rmsnorm_gate_up_activate_decode: the C ABI's argument checks, the two-launch fallback on a narrow layer (the same bytes), and the
+    queries' answers past the decode sizes"""
+    import torch
+    lib = _lib.load()
+    rng = np.random.default_rng(5)
+    m, h, i, in_split, dsplit = 2, 384, 512, (128, 128, 128), (256, 128, 128)          # 2 I / 64 = 16 workgroups: not a wide layer
+    x = t_from_bits(make_inputs(rng, m, h), dev)
+    nw = t_from_bits(o.f32_to_bf16((1.0 + 0.2 * rng.standard_normal(h)).astype(np.float32)), dev)
+    idx = torch.from_numpy(rng.permutation(h).astype(np.int16)).to(dev)
+    qg = mixedgemm.reorder_quantize_w4(t_from_bits(make_inputs(rng, i, h, "weight"), dev) * 8, idx, *in_split)
+    qu = mixedgemm.reorder_quantize_w4(t_from_bits(make_inputs(rng, i, h, "weight"), dev) * 8, idx, *in_split)
+    qgu = mixedgemm.interleave_gate_up(qg, qu)
+    assert mixedgemm.rmsnorm_gate_up_activate_decode_supported(m, i, *in_split) == 1
+    want = three_op(mixedgemm.rmsnorm_quantize_x(x, nw, 1e-5, idx, *in_split), qg, qu, dsplit)
+    assert_same_operands(mixedgemm.rmsnorm_gate_up_activate_decode(x, nw, 1e-5, idx, qgu, *dsplit), want, m, dsplit, "narrow layer, two launches")
+    want_nr = three_op(mixedgemm.rmsnorm_quantize_x(x, nw, 1e-5, idx, *in_split, integer_round=False), qg, qu, dsplit)
+    got_nr = mixedgemm.rmsnorm_gate_up_activate_decode(x, nw, 1e-5, idx, qgu, *dsplit, integer_round=False)
+    assert_same_operands(got_nr, want_nr, m, dsplit, "no integer round")
+    # queries: nothing past the decode sizes, nothing for a bad split
+    assert mixedgemm.rmsnorm_gate_up_activate_decode_supported(9, 14336, 2048, 128, 1920) == 0
+    assert mixedgemm.gate_up_activate_decode_supported(9, 14336, 2048, 128, 1920) == 0
+    assert lib.mm_rmsnorm_gate_up_activate_decode_supported(1, 14336, 2048, 100, 1948) == 0
+    assert lib.mm_rmsnorm_gate_up_activate_decode_supported(1, 14300, 2048, 128, 1920) == 0
+    with pytest.raises(RuntimeError, match="Value error in run_activate_quantize_x"):
+        mixedgemm.rmsnorm_gate_up_activate_decode(x, nw, 1e-5, idx, qgu, 256, 128, 0)              # does not sum to I
+    with pytest.raises(RuntimeError):
+        mixedgemm.rmsnorm_gate_up_activate_decode(torch.cat([x] * 5)[:9].contiguous(), nw, 1e-5, idx, qgu, *dsplit)      # M = 9
+    # C ABI: null pointers, misaligned rows, unknown flag bits
+    p = lambda t: t.data_ptr() if t.numel() else None
+    outs = [torch.empty_like(t) for t in want]
+    args = lambda xp, wp, flags: lib.mm_rmsnorm_gate_up_activate_decode(xp, wp, 1e-5, p(idx), *[p(t) for t in qgu], m, i, *in_split, *dsplit, flags,
+                                                                      *[p(t) for t in outs], None, 0, None)
+    assert args(None, p(nw), 0) != 0 and args(p(x) + 2, p(nw), 0) != 0 and args(p(x), None, 0) != 0 and args(p(x), p(nw), 0x40) != 0
+    assert args(p(x), p(nw), 0) != 0          # the narrow layer needs the workspace of the two-launch form
+    assert lib.mm_rmsnorm_gate_up_activate_decode(p(x), p(nw), 1e-5, p(idx), *[p(t) for t in qgu], 0, i, *in_split, *dsplit, 0, *[p(t) for t in outs],
+                                                  None, 0, None) == 0      # M = 0: nothing to do
